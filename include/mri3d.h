@@ -1,0 +1,189 @@
+/*
+ * mri3d.h — C ABI of libmri3d_hip.so: the MI355X (gfx950) volumetric operator set behind the
+ * 3-D U-Net / separable-conv encoder training path of kondratevakate/mri-epilepsy-diagnosis.
+ *
+ * The reference has no native layer: its hot path is `model(inputs)` / `loss.backward()` on torch.nn
+ * modules (segmentation/routine.py:255-278, classification/routine.py:28-34).  Each entry point below
+ * replaces one torch.nn operator that those calls reach; the reference call site is cited per function.
+ *
+ * Conventions
+ *   - All tensors are device pointers into memory owned by the caller (PyTorch's caching allocator).
+ *     The library never allocates, frees or synchronises; every kernel is enqueued on `stream`.
+ *   - Activations are NDHWC ("channels-last-3d"): element (n,d,h,w,c) of a tensor with pitch `ld`
+ *     lives at ((((n*D + d)*H + h)*W + w) * ld + c).  ld >= C lets an operator read or write a channel
+ *     slice of a wider buffer (decoder concat buffers) without a copy.
+ *   - Weights keep torch's parameter layout (Cout, Cin, kd, kh, kw) so state_dicts stay compatible;
+ *     kernels repack into `workspace` on the fly.
+ *   - dtype: MRI3D_F32 only in this revision (MRI3D_BF16 is reserved and returns MRI3D_ENOTSUP).
+ *   - Return value: 0 = OK, negative = error; mri3d_last_error() gives a thread-local message.
+ *   - Reductions are deterministic (no floating-point atomics).
+ */
+#ifndef MRI3D_H
+#define MRI3D_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* mri3d_stream_t; /* hipStream_t */
+
+enum { MRI3D_OK = 0, MRI3D_EINVAL = -1, MRI3D_ENOTSUP = -2, MRI3D_ELAUNCH = -3, MRI3D_EWORKSPACE = -4 };
+enum { MRI3D_F32 = 0, MRI3D_BF16 = 1 };
+enum { MRI3D_ACT_NONE = 0, MRI3D_ACT_RELU = 1, MRI3D_ACT_LEAKY = 2, MRI3D_ACT_PRELU = 3 };
+enum { MRI3D_UP_NEAREST = 0, MRI3D_UP_TRILINEAR = 1 };
+enum { MRI3D_PASS_FWD = 0, MRI3D_PASS_DGRAD = 1, MRI3D_PASS_WGRAD = 2 };
+
+int mri3d_version(void);
+const char* mri3d_last_error(void);
+
+/* ------------------------------------------------------------------------------------------------
+ * Conv3d — replaces torch.nn.Conv3d as used by unet.UNet (segmentation/routine.py:346-356),
+ * AE_model.DownBlock/UpBlock (classification/models/AE_model.py:9-26,74-91), cnn_model (cnn_model.py:14,49-148),
+ * Modified3DUNet (segmentation/models/modified_3dunet.py:17-80).
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct Mri3dConvGeom {
+    int32_t n;                 /* batch */
+    int32_t di, hi, wi, ci;    /* input  D,H,W,C */
+    int32_t dout, ho, wo, co;  /* output D,H,W,C */
+    int32_t kd, kh, kw;        /* kernel */
+    int32_t sd, sh, sw;        /* stride */
+    int32_t pd, ph, pw;        /* zero padding */
+    int32_t dd, dh, dw;        /* dilation */
+    int32_t x_ld, y_ld;        /* voxel pitch (elements) of the input / output buffers */
+    int32_t dtype;             /* MRI3D_F32 */
+} Mri3dConvGeom;
+
+size_t mri3d_conv3d_workspace_bytes(const Mri3dConvGeom* g, int pass);
+
+/* y = conv(x, w) + bias.  bias may be NULL. */
+int mri3d_conv3d_fwd(const Mri3dConvGeom* g, const void* x, const void* w, const void* bias, void* y,
+                     void* workspace, size_t ws_bytes, mri3d_stream_t stream);
+/* dx = conv_transpose(dy, w) (+ bias, used when this is the forward of a ConvTranspose3d). dx has pitch x_ld. */
+int mri3d_conv3d_dgrad(const Mri3dConvGeom* g, const void* dy, const void* w, const void* bias, void* dx,
+                       void* workspace, size_t ws_bytes, mri3d_stream_t stream);
+/* dw (torch layout) = sum_v x (*) dy ; dbias = sum_v dy (dbias may be NULL). */
+int mri3d_conv3d_wgrad(const Mri3dConvGeom* g, const void* x, const void* dy, void* dw, void* dbias,
+                       void* workspace, size_t ws_bytes, mri3d_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * BatchNorm3d / InstanceNorm3d fused with the following activation — replaces
+ * nn.BatchNorm3d + nn.PReLU (unet.UNet ConvolutionalBlock), nn.BatchNorm3d + LeakyReLU/ReLU
+ * (AE_model.py:30-36, cnn_model.py), nn.InstanceNorm3d + LeakyReLU (modified_3dunet.py:20-94).
+ * groups = 1 (batch norm: statistics over n*vox per channel) or n (instance norm: per (n,c)).
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct Mri3dNormGeom {
+    int32_t n;        /* batch */
+    int64_t vox;      /* D*H*W */
+    int32_t c;        /* channels */
+    int32_t x_ld;     /* voxel pitch of x / dx */
+    int32_t y_ld;     /* voxel pitch of y / dy */
+    int32_t instance; /* 0 = batch statistics, 1 = per-instance statistics */
+    int32_t act;      /* MRI3D_ACT_* applied after the affine transform */
+    int32_t alpha_n;  /* PReLU: number of alpha parameters (1 or c) */
+    float slope;      /* LeakyReLU negative slope */
+    float eps;
+    int32_t dtype;
+} Mri3dNormGeom;
+
+size_t mri3d_norm_workspace_bytes(const Mri3dNormGeom* g);
+
+/* mean/invstd: [groups*c] floats where groups = instance ? n : 1.
+ * If running_mean/running_var are non-NULL (batch mode only) they are updated in place:
+ *   running = (1-momentum)*running + momentum*stat, with the unbiased variance, as torch does. */
+int mri3d_norm_stats(const Mri3dNormGeom* g, const void* x, float* mean, float* invstd,
+                     float* running_mean, float* running_var, float momentum,
+                     void* workspace, size_t ws_bytes, mri3d_stream_t stream);
+/* y = act(gamma * (x - mean) * invstd + beta).  gamma/beta may be NULL (affine=False); alpha is the
+ * PReLU parameter (device pointer) when act == MRI3D_ACT_PRELU.  mean/invstd NULL => identity norm. */
+int mri3d_norm_act_fwd(const Mri3dNormGeom* g, const void* x, const float* mean, const float* invstd,
+                       const float* gamma, const float* beta, const float* alpha, void* y,
+                       mri3d_stream_t stream);
+/* Backward of norm_act_fwd.  training != 0: statistics were computed from x (batch/instance mode);
+ * training == 0: mean/invstd are constants (eval-mode BatchNorm).  dgamma/dbeta/dalpha may be NULL. */
+int mri3d_norm_act_bwd(const Mri3dNormGeom* g, int training, const void* x, const void* dy,
+                       const float* mean, const float* invstd, const float* gamma, const float* beta,
+                       const float* alpha, void* dx, float* dgamma, float* dbeta, float* dalpha,
+                       void* workspace, size_t ws_bytes, mri3d_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * MaxPool3d — nn.MaxPool3d(2) in unet.UNet / AE_model.py:27 / cnn_model.py:115-148, (4,2) in cnn_model.py:221,232.
+ * idx: one byte per output element = window-local offset (kd,kh,kw raster) of the arg-max.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct Mri3dPoolGeom {
+    int32_t n, di, hi, wi, dout, ho, wo, c;
+    int32_t kd, kh, kw, sd, sh, sw, pd, ph, pw;
+    int32_t x_ld, y_ld;
+    int32_t dtype;
+} Mri3dPoolGeom;
+int mri3d_maxpool3d_fwd(const Mri3dPoolGeom* g, const void* x, void* y, uint8_t* idx, mri3d_stream_t stream);
+int mri3d_maxpool3d_bwd(const Mri3dPoolGeom* g, const void* dy, const uint8_t* idx, void* dx, mri3d_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Upsample — nn.Upsample(scale_factor=2, mode='trilinear', align_corners=False) (unet.UNet decoder),
+ * mode='nearest' (modified_3dunet.py:13, AE_model.py:70-73), F.interpolate(size=...) (AE_model.py:119).
+ * rd/rh/rw: source step per destination step (torch's "scale" = 1/scale_factor, or in/out for size=).
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct Mri3dUpGeom {
+    int32_t n, di, hi, wi, dout, ho, wo, c;
+    int32_t x_ld, y_ld;
+    int32_t mode;          /* MRI3D_UP_* */
+    int32_t align_corners; /* trilinear only */
+    float rd, rh, rw;
+    int32_t dtype;
+} Mri3dUpGeom;
+size_t mri3d_upsample3d_workspace_bytes(const Mri3dUpGeom* g);
+int mri3d_upsample3d_fwd(const Mri3dUpGeom* g, const void* x, void* y, mri3d_stream_t stream);
+int mri3d_upsample3d_bwd(const Mri3dUpGeom* g, const void* dy, void* dx, void* workspace, size_t ws_bytes,
+                         mri3d_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Fused softmax(dim=C) + soft-Dice loss — F.softmax + get_dice_loss + .mean()
+ * (segmentation/routine.py:239-253,272-274).  target has ct = 1 (broadcast over classes, the
+ * reference's behaviour) or ct = c channels.  stats: [n*c*3] floats (tp, sum_p, sum_g) kept for bwd.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct Mri3dDiceGeom {
+    int32_t n;
+    int64_t vox;
+    int32_t c, ct;
+    int32_t x_ld, t_ld;
+    float eps;
+    int32_t dtype;
+} Mri3dDiceGeom;
+size_t mri3d_softmax_dice_workspace_bytes(const Mri3dDiceGeom* g);
+int mri3d_softmax_dice_fwd(const Mri3dDiceGeom* g, const void* logits, const void* target, float* loss,
+                           float* stats, void* workspace, size_t ws_bytes, mri3d_stream_t stream);
+/* dlogits = dloss * d(loss)/d(logits); dloss is a device pointer to one float. */
+int mri3d_softmax_dice_bwd(const Mri3dDiceGeom* g, const void* logits, const void* target, const float* stats,
+                           const float* dloss, void* dlogits, mri3d_stream_t stream);
+
+/* argmax over channels -> uint8 mask (validate_dsc_asd, segmentation/routine.py:226-227). First max wins. */
+int mri3d_argmax_u8(const void* logits, uint8_t* out, int64_t nvox, int32_t c, int32_t ld, int32_t dtype,
+                    mri3d_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Channel-slice plumbing: torch.cat along channels (unet.UNet decoder, modified_3dunet.py:158-178) and
+ * residual adds (modified_3dunet.py:108, cnn_model.py:34).
+ *   copy: dst[v, 0:c] = src[v, 0:c]      add: dst[v, 0:c] = a[v,0:c] + b[v,0:c]
+ * ---------------------------------------------------------------------------------------------- */
+int mri3d_copy_channels(const void* src, void* dst, int64_t nvox, int32_t c, int32_t src_ld, int32_t dst_ld,
+                        int32_t dtype, mri3d_stream_t stream);
+int mri3d_add_channels(const void* a, const void* b, void* dst, int64_t nvox, int32_t c, int32_t a_ld,
+                       int32_t b_ld, int32_t dst_ld, int32_t dtype, mri3d_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * AdamW / Adam on one flat fp32 buffer — torch.optim.AdamW (segmentation/routine.py:358) and
+ * torch.optim.Adam with L2 weight_decay (classification/routine.py:271,275).
+ * grad_scale multiplies the gradient first (1/world_size after the RCCL sum all-reduce).
+ * decoupled != 0: AdamW (p *= 1 - lr*wd); decoupled == 0: Adam (g += wd*p).
+ * ---------------------------------------------------------------------------------------------- */
+int mri3d_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
+                    float eps, float weight_decay, int32_t step, float grad_scale, int32_t decoupled,
+                    mri3d_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MRI3D_H */

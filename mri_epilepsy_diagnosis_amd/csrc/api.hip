@@ -1,0 +1,100 @@
+// api.hip — C-ABI entry points that are not tied to one kernel file: version, error string, and the Conv3d
+// dispatcher (generic direct kernels vs. the MFMA implicit-GEMM path for 3x3x3 stride-1 layers).
+#include "common.h"
+#include <string.h>
+
+namespace mri3d {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+// conv_generic.hip
+size_t conv_generic_workspace_bytes(const Mri3dConvGeom& g, int pass);
+int conv_generic_fwd(const Mri3dConvGeom& g, const float* x, const float* w, const float* bias, float* y, void* ws,
+                     size_t ws_bytes, hipStream_t s);
+int conv_generic_dgrad(const Mri3dConvGeom& g, const float* dy, const float* w, const float* bias, float* dx, void* ws,
+                       size_t ws_bytes, hipStream_t s);
+int conv_generic_wgrad(const Mri3dConvGeom& g, const float* x, const float* dy, float* dw, float* dbias, void* ws,
+                       size_t ws_bytes, hipStream_t s);
+// conv_mfma.hip
+bool conv_mfma_supported(const Mri3dConvGeom& g, int pass);
+size_t conv_mfma_workspace_bytes(const Mri3dConvGeom& g, int pass);
+int conv_mfma_fwd(const Mri3dConvGeom& g, const float* x, const float* w, const float* bias, float* y, void* ws,
+                  size_t ws_bytes, hipStream_t s);
+int conv_mfma_dgrad(const Mri3dConvGeom& g, const float* dy, const float* w, const float* bias, float* dx, void* ws,
+                    size_t ws_bytes, hipStream_t s);
+int conv_mfma_wgrad(const Mri3dConvGeom& g, const float* x, const float* dy, float* dw, float* dbias, void* ws,
+                    size_t ws_bytes, hipStream_t s);
+
+static int conv_check(const Mri3dConvGeom* g, const char* who) {
+    MRI3D_REQUIRE(g != nullptr, MRI3D_EINVAL, "%s: null geometry", who);
+    MRI3D_REQUIRE(g->dtype == MRI3D_F32, MRI3D_ENOTSUP, "%s: only MRI3D_F32 is implemented (dtype=%d)", who, g->dtype);
+    MRI3D_REQUIRE(g->n > 0 && g->di > 0 && g->hi > 0 && g->wi > 0 && g->ci > 0 && g->dout > 0 && g->ho > 0 && g->wo > 0 &&
+                      g->co > 0,
+                  MRI3D_EINVAL, "%s: empty tensor", who);
+    MRI3D_REQUIRE(g->kd > 0 && g->kh > 0 && g->kw > 0 && g->sd > 0 && g->sh > 0 && g->sw > 0 && g->dd > 0 && g->dh > 0 &&
+                      g->dw > 0 && g->pd >= 0 && g->ph >= 0 && g->pw >= 0,
+                  MRI3D_EINVAL, "%s: bad kernel/stride/padding/dilation", who);
+    MRI3D_REQUIRE(g->x_ld >= g->ci && g->y_ld >= g->co, MRI3D_EINVAL, "%s: pitch smaller than channel count", who);
+    // torch: out = floor((in + 2p - d(k-1) - 1)/s) + 1
+    int ed = (g->di + 2 * g->pd - g->dd * (g->kd - 1) - 1) / g->sd + 1;
+    int eh = (g->hi + 2 * g->ph - g->dh * (g->kh - 1) - 1) / g->sh + 1;
+    int ew = (g->wi + 2 * g->pw - g->dw * (g->kw - 1) - 1) / g->sw + 1;
+    MRI3D_REQUIRE(ed == g->dout && eh == g->ho && ew == g->wo, MRI3D_EINVAL,
+                  "%s: output dims (%d,%d,%d) do not match conv arithmetic (%d,%d,%d)", who, g->dout, g->ho, g->wo, ed, eh,
+                  ew);
+    return MRI3D_OK;
+}
+
+}  // namespace mri3d
+
+using namespace mri3d;
+
+extern "C" int mri3d_version(void) { return 100; }  // 0.1.0
+extern "C" const char* mri3d_last_error(void) { return g_err; }
+
+extern "C" size_t mri3d_conv3d_workspace_bytes(const Mri3dConvGeom* g, int pass) {
+    if (!g) return 0;
+    size_t a = conv_generic_workspace_bytes(*g, pass);
+    size_t b = conv_mfma_supported(*g, pass) ? conv_mfma_workspace_bytes(*g, pass) : 0;
+    return align_up(a > b ? a : b, 256);
+}
+
+extern "C" int mri3d_conv3d_fwd(const Mri3dConvGeom* g, const void* x, const void* w, const void* bias, void* y,
+                                void* workspace, size_t ws_bytes, mri3d_stream_t stream) {
+    int rc = conv_check(g, "conv3d_fwd");
+    if (rc) return rc;
+    MRI3D_REQUIRE(x && w && y, MRI3D_EINVAL, "conv3d_fwd: null pointer");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (conv_mfma_supported(*g, MRI3D_PASS_FWD))
+        return conv_mfma_fwd(*g, (const float*)x, (const float*)w, (const float*)bias, (float*)y, workspace, ws_bytes, s);
+    return conv_generic_fwd(*g, (const float*)x, (const float*)w, (const float*)bias, (float*)y, workspace, ws_bytes, s);
+}
+
+extern "C" int mri3d_conv3d_dgrad(const Mri3dConvGeom* g, const void* dy, const void* w, const void* bias, void* dx,
+                                  void* workspace, size_t ws_bytes, mri3d_stream_t stream) {
+    int rc = conv_check(g, "conv3d_dgrad");
+    if (rc) return rc;
+    MRI3D_REQUIRE(dy && w && dx, MRI3D_EINVAL, "conv3d_dgrad: null pointer");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (conv_mfma_supported(*g, MRI3D_PASS_DGRAD))
+        return conv_mfma_dgrad(*g, (const float*)dy, (const float*)w, (const float*)bias, (float*)dx, workspace, ws_bytes, s);
+    return conv_generic_dgrad(*g, (const float*)dy, (const float*)w, (const float*)bias, (float*)dx, workspace, ws_bytes, s);
+}
+
+extern "C" int mri3d_conv3d_wgrad(const Mri3dConvGeom* g, const void* x, const void* dy, void* dw, void* dbias,
+                                  void* workspace, size_t ws_bytes, mri3d_stream_t stream) {
+    int rc = conv_check(g, "conv3d_wgrad");
+    if (rc) return rc;
+    MRI3D_REQUIRE(x && dy && dw, MRI3D_EINVAL, "conv3d_wgrad: null pointer");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (conv_mfma_supported(*g, MRI3D_PASS_WGRAD))
+        return conv_mfma_wgrad(*g, (const float*)x, (const float*)dy, (float*)dw, (float*)dbias, workspace, ws_bytes, s);
+    return conv_generic_wgrad(*g, (const float*)x, (const float*)dy, (float*)dw, (float*)dbias, workspace, ws_bytes, s);
+}

@@ -1,0 +1,234 @@
+// loss.hip — fused softmax(dim=C) + soft-Dice loss and its gradient, plus the argmax->uint8 mask used by validation.
+// Reference: F.softmax(logits, dim=1) -> get_dice_loss(probabilities, targets) -> .mean()
+// (segmentation/routine.py:239-253, 272-274); labels = logits.argmax(dim=1) (routine.py:226-227).
+//
+//   p = softmax(z);  tp_c = sum p_c g_c,  fp_c = sum p_c (1-g_c),  fn_c = sum (1-p_c) g_c
+//   dice_c = 2 tp_c / (2 tp_c + fp_c + fn_c + eps) = 2 tp_c / (sum p_c + sum g_c + eps)
+//   loss = mean_{n,c} (1 - dice_{n,c})
+// The reference feeds a (N,1,...) target against (N,2,...) probabilities, i.e. g_c = g for every class (SURVEY
+// Appendix C.1); ct == 1 reproduces that broadcast, ct == c is the per-class form.
+//
+// HBM-bound: forward = one read of logits+target; backward = one read of both + one write of dlogits.
+#include "common.h"
+
+namespace mri3d {
+
+constexpr int kDiceMaxC = 8;
+constexpr int kDiceMaxBlocks = 1024;
+
+template <int C>
+__device__ __forceinline__ void softmax_c(const float* z, float (&p)[C]) {
+    float m = z[0];
+#pragma unroll
+    for (int j = 1; j < C; ++j) m = fmaxf(m, z[j]);
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < C; ++j) { p[j] = expf(z[j] - m); s += p[j]; }
+    float inv = 1.f / s;
+#pragma unroll
+    for (int j = 0; j < C; ++j) p[j] *= inv;
+}
+
+// part[n][blk][c][3] = (tp, sum_p, sum_g)
+template <int C>
+__global__ void __launch_bounds__(256)
+dice_fwd_kernel(const float* __restrict__ logits, const float* __restrict__ target, float* __restrict__ part,
+                int64_t vox, int ct, int x_ld, int t_ld) {
+    __shared__ float red[4][C * 3];
+    const int n = blockIdx.y;
+    const float* zn = logits + (int64_t)n * vox * x_ld;
+    const float* tn = target + (int64_t)n * vox * t_ld;
+    float tp[C], sp[C], sg[C];
+#pragma unroll
+    for (int j = 0; j < C; ++j) { tp[j] = 0.f; sp[j] = 0.f; sg[j] = 0.f; }
+    for (int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; v < vox; v += (int64_t)gridDim.x * blockDim.x) {
+        float z[C], p[C];
+#pragma unroll
+        for (int j = 0; j < C; ++j) z[j] = zn[v * x_ld + j];
+        softmax_c<C>(z, p);
+#pragma unroll
+        for (int j = 0; j < C; ++j) {
+            float g = tn[v * t_ld + (ct == 1 ? 0 : j)];
+            tp[j] = fmaf(p[j], g, tp[j]);
+            sp[j] += p[j];
+            sg[j] += g;
+        }
+    }
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+#pragma unroll
+    for (int j = 0; j < C; ++j) {
+        float a = wave_sum(tp[j]), b = wave_sum(sp[j]), c = wave_sum(sg[j]);
+        if (lane == 0) { red[wave][j * 3] = a; red[wave][j * 3 + 1] = b; red[wave][j * 3 + 2] = c; }
+    }
+    __syncthreads();
+    if (threadIdx.x < C * 3) {
+        float s = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+        part[((size_t)n * gridDim.x + blockIdx.x) * C * 3 + threadIdx.x] = s;
+    }
+}
+
+// one block: stats[n][c][3] and the scalar loss
+__global__ void dice_finalize_kernel(const float* __restrict__ part, float* __restrict__ stats, float* __restrict__ loss,
+                                     int N, int C, int nblk, float eps) {
+    __shared__ double acc[256];
+    double my = 0.0;
+    for (int i = threadIdx.x; i < N * C; i += blockDim.x) {
+        int n = i / C, c = i - n * C;
+        double tp = 0.0, sp = 0.0, sg = 0.0;
+        const float* p = part + ((size_t)n * nblk * C + c) * 3;
+        for (int q = 0; q < nblk; ++q) {
+            tp += (double)p[(size_t)q * C * 3];
+            sp += (double)p[(size_t)q * C * 3 + 1];
+            sg += (double)p[(size_t)q * C * 3 + 2];
+        }
+        stats[i * 3] = (float)tp;
+        stats[i * 3 + 1] = (float)sp;
+        stats[i * 3 + 2] = (float)sg;
+        // float arithmetic from here mirrors the reference's fp32 tensors
+        float ftp = (float)tp, den = 2.f * ftp + ((float)sp - ftp) + ((float)sg - ftp) + eps;
+        my += 1.0 - (double)(2.f * ftp / den);
+    }
+    acc[threadIdx.x] = my;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double t = 0.0;
+        for (int i = 0; i < (int)blockDim.x; ++i) t += acc[i];
+        loss[0] = (float)(t / (double)(N * C));
+    }
+}
+
+template <int C>
+__global__ void __launch_bounds__(256)
+dice_bwd_kernel(const float* __restrict__ logits, const float* __restrict__ target, const float* __restrict__ stats,
+                const float* __restrict__ dloss, float* __restrict__ dlogits, int64_t vox, int N, int ct, int x_ld,
+                int t_ld, float eps) {
+    const int n = blockIdx.y;
+    const float* zn = logits + (int64_t)n * vox * x_ld;
+    const float* tn = target + (int64_t)n * vox * t_ld;
+    float* dn = dlogits + (int64_t)n * vox * x_ld;
+    // d(1 - dice)/dp_c(v) = -(2 g den - 2 tp)/den^2, scaled by dloss/(N*C)
+    float ka[C], kb[C];
+    const float scale = dloss[0] / (float)(N * C);
+#pragma unroll
+    for (int j = 0; j < C; ++j) {
+        float tp = stats[(n * C + j) * 3], sp = stats[(n * C + j) * 3 + 1], sg = stats[(n * C + j) * 3 + 2];
+        float den = sp + sg + eps;
+        ka[j] = -2.f * scale / den;          // multiplies g
+        kb[j] = 2.f * scale * tp / (den * den);  // constant term
+    }
+    for (int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; v < vox; v += (int64_t)gridDim.x * blockDim.x) {
+        float z[C], p[C], dp[C];
+#pragma unroll
+        for (int j = 0; j < C; ++j) z[j] = zn[v * x_ld + j];
+        softmax_c<C>(z, p);
+        float dot = 0.f;
+#pragma unroll
+        for (int j = 0; j < C; ++j) {
+            float g = tn[v * t_ld + (ct == 1 ? 0 : j)];
+            dp[j] = fmaf(ka[j], g, kb[j]);
+            dot = fmaf(p[j], dp[j], dot);
+        }
+#pragma unroll
+        for (int j = 0; j < C; ++j) dn[v * x_ld + j] = p[j] * (dp[j] - dot);
+    }
+}
+
+__global__ void __launch_bounds__(256)
+argmax_u8_kernel(const float* __restrict__ logits, uint8_t* __restrict__ out, int64_t nvox, int C, int ld) {
+    for (int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; v < nvox; v += (int64_t)gridDim.x * blockDim.x) {
+        const float* z = logits + v * ld;
+        float best = z[0];
+        int bi = 0;
+        for (int j = 1; j < C; ++j) {
+            float t = z[j];
+            // torch.argmax: first maximal value; NaN counts as maximal
+            if ((t > best && best == best) || (t != t && best == best)) { best = t; bi = j; }
+        }
+        out[v] = (uint8_t)bi;
+    }
+}
+
+static int dice_blocks(const Mri3dDiceGeom& g) {
+    int64_t want = cdiv64(g.vox, 256 * 4);
+    int cap = kDiceMaxBlocks / g.n;
+    if (cap < 1) cap = 1;
+    int b = (int)(want < cap ? want : cap);
+    return b < 1 ? 1 : b;
+}
+
+}  // namespace mri3d
+
+using namespace mri3d;
+
+static int dice_check(const Mri3dDiceGeom* g, const char* who) {
+    MRI3D_REQUIRE(g != nullptr, MRI3D_EINVAL, "%s: null geometry", who);
+    MRI3D_REQUIRE(g->dtype == MRI3D_F32, MRI3D_ENOTSUP, "%s: only MRI3D_F32 is implemented", who);
+    MRI3D_REQUIRE(g->n > 0 && g->vox > 0, MRI3D_EINVAL, "%s: empty tensor", who);
+    MRI3D_REQUIRE(g->c >= 2 && g->c <= kDiceMaxC, MRI3D_ENOTSUP, "%s: classes must be in [2,%d], got %d", who, kDiceMaxC,
+                  g->c);
+    MRI3D_REQUIRE(g->ct == 1 || g->ct == g->c, MRI3D_EINVAL, "%s: target channels %d must be 1 or %d", who, g->ct, g->c);
+    MRI3D_REQUIRE(g->x_ld >= g->c && g->t_ld >= g->ct, MRI3D_EINVAL, "%s: bad pitch", who);
+    return MRI3D_OK;
+}
+
+extern "C" size_t mri3d_softmax_dice_workspace_bytes(const Mri3dDiceGeom* g) {
+    if (!g) return 0;
+    return (size_t)(kDiceMaxBlocks + g->n) * g->c * 3 * sizeof(float);
+}
+
+#define DICE_DISPATCH(CALL)                 \
+    switch (g->c) {                         \
+        case 2: CALL(2); break;             \
+        case 3: CALL(3); break;             \
+        case 4: CALL(4); break;             \
+        case 5: CALL(5); break;             \
+        case 6: CALL(6); break;             \
+        case 7: CALL(7); break;             \
+        default: CALL(8); break;            \
+    }
+
+extern "C" int mri3d_softmax_dice_fwd(const Mri3dDiceGeom* g, const void* logits, const void* target, float* loss,
+                                      float* stats, void* workspace, size_t ws_bytes, mri3d_stream_t stream) {
+    int rc = dice_check(g, "softmax_dice_fwd");
+    if (rc) return rc;
+    MRI3D_REQUIRE(logits && target && loss && stats, MRI3D_EINVAL, "softmax_dice_fwd: null pointer");
+    MRI3D_REQUIRE(workspace && ws_bytes >= mri3d_softmax_dice_workspace_bytes(g), MRI3D_EWORKSPACE,
+                  "softmax_dice_fwd: workspace %zu < %zu", ws_bytes, mri3d_softmax_dice_workspace_bytes(g));
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    int nblk = dice_blocks(*g);
+    float* part = static_cast<float*>(workspace);
+#define CALL(CC)                                                                                              \
+    hipLaunchKernelGGL(dice_fwd_kernel<CC>, dim3(nblk, g->n), dim3(256), 0, s, (const float*)logits,          \
+                       (const float*)target, part, g->vox, g->ct, g->x_ld, g->t_ld)
+    DICE_DISPATCH(CALL)
+#undef CALL
+    hipLaunchKernelGGL(dice_finalize_kernel, dim3(1), dim3(256), 0, s, part, stats, loss, g->n, g->c, nblk, g->eps);
+    return check_launch("softmax_dice_fwd");
+}
+
+extern "C" int mri3d_softmax_dice_bwd(const Mri3dDiceGeom* g, const void* logits, const void* target,
+                                      const float* stats, const float* dloss, void* dlogits, mri3d_stream_t stream) {
+    int rc = dice_check(g, "softmax_dice_bwd");
+    if (rc) return rc;
+    MRI3D_REQUIRE(logits && target && stats && dloss && dlogits, MRI3D_EINVAL, "softmax_dice_bwd: null pointer");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    int nblk = stream_grid(g->vox, 256);
+    if (nblk * g->n > 4096) nblk = 4096 / g->n > 0 ? 4096 / g->n : 1;
+#define CALL(CC)                                                                                              \
+    hipLaunchKernelGGL(dice_bwd_kernel<CC>, dim3(nblk, g->n), dim3(256), 0, s, (const float*)logits,          \
+                       (const float*)target, stats, dloss, (float*)dlogits, g->vox, g->n, g->ct, g->x_ld,    \
+                       g->t_ld, g->eps)
+    DICE_DISPATCH(CALL)
+#undef CALL
+    return check_launch("softmax_dice_bwd");
+}
+
+extern "C" int mri3d_argmax_u8(const void* logits, uint8_t* out, int64_t nvox, int32_t c, int32_t ld, int32_t dtype,
+                               mri3d_stream_t stream) {
+    MRI3D_REQUIRE(dtype == MRI3D_F32, MRI3D_ENOTSUP, "argmax_u8: only MRI3D_F32 is implemented");
+    MRI3D_REQUIRE(logits && out && nvox > 0 && c > 0 && c <= 256 && ld >= c, MRI3D_EINVAL, "argmax_u8: bad arguments");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    hipLaunchKernelGGL(argmax_u8_kernel, dim3(stream_grid(nvox, 256)), dim3(256), 0, s, (const float*)logits, out, nvox,
+                       c, ld);
+    return check_launch("argmax_u8");
+}

@@ -1,0 +1,501 @@
+// norm.hip — BatchNorm3d / InstanceNorm3d statistics, fused normalise+affine+activation forward, and the fused
+// backward (activation' -> dgamma/dbeta/dalpha reductions -> dx), NDHWC with voxel pitch.
+// Reference semantics: torch.nn.BatchNorm3d (eps 1e-5, momentum .1, biased var for normalisation, unbiased for the
+// running estimate) + nn.PReLU / LeakyReLU / ReLU as used by unet.UNet blocks, AE_model.py:30-36, cnn_model.py,
+// modified_3dunet.py:20-94 (InstanceNorm3d, affine=False).
+//
+// Roofline: pure streaming (HBM-bound).  Algorithmic bytes: stats = 1 read of x; fwd apply = 1 read + 1 write;
+// bwd = 2 reads (x,dy) for the reductions + 2 reads + 1 write for dx.
+//
+// Thread mapping: a 256-thread block is a (VT voxels) x (CL channel-lanes) grid, each lane owning VEC consecutive
+// channels, so a thread's channels never change across the grid-stride loop: per-channel partial sums live in
+// registers, are combined across the VT voxel rows through LDS once per block, and one partial per block goes to
+// the workspace.  A finalize kernel sums the partials in a fixed order in double precision (deterministic).
+#include "common.h"
+
+namespace mri3d {
+
+struct NormPlan {
+    int vec;     // channels per lane (4 or 1)
+    int CL;      // channel lanes per voxel row handled by one block (<= 256)
+    int VT;      // voxel rows per block iteration
+    int cy;      // grid.y = channel chunks
+    int nblk;    // grid.x = blocks per group
+    int groups;  // grid.z
+    int64_t gvox;  // voxels per group
+};
+
+constexpr int kNormMaxBlocks = 1024;  // 4 blocks/CU of streaming work; keeps the finalize pass short
+constexpr int kFinQL = 16;            // partial-sum lanes per channel in the finalize kernels
+
+static inline bool aligned16(const void* a, const void* b = nullptr, const void* c = nullptr) {
+    return ((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(b) | reinterpret_cast<uintptr_t>(c)) & 15) == 0;
+}
+
+static NormPlan norm_plan(const Mri3dNormGeom& g, bool al) {
+    NormPlan p;
+    p.vec = (g.c % 4 == 0 && g.x_ld % 4 == 0 && g.y_ld % 4 == 0 && al) ? 4 : 1;
+    int lanes = g.c / p.vec;
+    p.CL = lanes < 256 ? lanes : 256;
+    p.cy = cdiv(lanes, p.CL);
+    p.VT = 256 / p.CL;
+    p.groups = g.instance ? g.n : 1;
+    p.gvox = g.instance ? g.vox : (int64_t)g.n * g.vox;
+    int64_t want = cdiv64(p.gvox, (int64_t)p.VT * 8);  // >= 8 voxel rows per thread
+    int cap = kNormMaxBlocks / (p.groups * p.cy);
+    if (cap < 1) cap = 1;
+    p.nblk = (int)(want < cap ? want : cap);
+    if (p.nblk < 1) p.nblk = 1;
+    return p;
+}
+
+size_t norm_workspace_floats(const Mri3dNormGeom& g) {
+    // plan with worst-case (vec=1) block count is not needed: nblk <= kMaxStreamBlocks/groups always.
+    int groups = g.instance ? g.n : 1;
+    size_t part = (size_t)(kNormMaxBlocks + groups) * g.c * 3;  // per-block partials (groups*nblk <= kNormMaxBlocks, or nblk=1)
+    part += (size_t)groups * g.c * 3;                           // bwd per-(group,channel) sums
+    return part;
+}
+
+template <int VEC>
+struct Ld {
+    static __device__ __forceinline__ void load(const float* p, float (&v)[VEC]) {
+        if (VEC == 4) {
+            float4 t = *reinterpret_cast<const float4*>(p);
+            v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+        } else {
+            v[0] = *p;
+        }
+    }
+    static __device__ __forceinline__ void store(float* p, const float (&v)[VEC]) {
+        if (VEC == 4) {
+            *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
+        } else {
+            *p = v[0];
+        }
+    }
+};
+
+// ------------------------------------------------------------------ statistics
+// partial layout: part[((group*cy... flattened as [group][blk][c][2]
+template <int VEC>
+__global__ void __launch_bounds__(256)
+norm_stats_kernel(const float* __restrict__ x, float* __restrict__ part, int C, int ld, int64_t gvox, int CL, int VT) {
+    __shared__ float red[256 * 2 * VEC];
+    const int tid = threadIdx.x;
+    const int cl = tid % CL, vt = tid / CL;
+    const int c0 = (blockIdx.y * CL + cl) * VEC;
+    const bool active = vt < VT && c0 < C;
+    const int group = blockIdx.z;
+    const float* xg = x + (int64_t)group * gvox * ld;
+    float s[VEC], ss[VEC], k[VEC];
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) { s[j] = 0.f; ss[j] = 0.f; k[j] = 0.f; }
+    if (active) {
+        Ld<VEC>::load(xg + c0, k);  // shift = first voxel of the group: removes E[x^2]-E[x]^2 cancellation
+        for (int64_t v = (int64_t)blockIdx.x * VT + vt; v < gvox; v += (int64_t)gridDim.x * VT) {
+            float xv[VEC];
+            Ld<VEC>::load(xg + v * ld + c0, xv);
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) {
+                float d = xv[j] - k[j];
+                s[j] += d;
+                ss[j] = fmaf(d, d, ss[j]);
+            }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) { red[(tid * VEC + j) * 2] = s[j]; red[(tid * VEC + j) * 2 + 1] = ss[j]; }
+    __syncthreads();
+    if (vt == 0 && c0 < C) {
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) {
+            float a = 0.f, b = 0.f;
+            for (int q = 0; q < VT; ++q) {
+                a += red[((q * CL + cl) * VEC + j) * 2];
+                b += red[((q * CL + cl) * VEC + j) * 2 + 1];
+            }
+            float* o = part + (((size_t)group * gridDim.x + blockIdx.x) * C + c0 + j) * 2;
+            o[0] = a;
+            o[1] = b;
+        }
+    }
+}
+
+__global__ void __launch_bounds__(256)
+norm_stats_finalize_kernel(const float* __restrict__ x, const float* __restrict__ part,
+                           float* __restrict__ mean, float* __restrict__ invstd,
+                           float* __restrict__ running_mean, float* __restrict__ running_var,
+                           float momentum, float eps, int C, int ld, int64_t gvox, int nblk, int groups) {
+    // 256 threads = 16 (group,channel) slots x kFinQL partial lanes
+    __shared__ double ra[256], rb[256];
+    const int slot = threadIdx.x / kFinQL, ql = threadIdx.x % kFinQL;
+    const int i = blockIdx.x * (256 / kFinQL) + slot;
+    const bool ok = i < groups * C;
+    const int group = ok ? i / C : 0, c = ok ? i - group * C : 0;
+    double a = 0.0, b = 0.0;
+    if (ok) {
+        const float* p = part + ((size_t)group * nblk * C + c) * 2;
+        for (int q = ql; q < nblk; q += kFinQL) {
+            a += (double)p[(size_t)q * C * 2];
+            b += (double)p[(size_t)q * C * 2 + 1];
+        }
+    }
+    ra[threadIdx.x] = a;
+    rb[threadIdx.x] = b;
+    __syncthreads();
+    if (!ok || ql != 0) return;
+    a = 0.0;
+    b = 0.0;
+    for (int q = 0; q < kFinQL; ++q) {
+        a += ra[slot * kFinQL + q];
+        b += rb[slot * kFinQL + q];
+    }
+    double k = (double)x[(int64_t)group * gvox * ld + c];
+    double cnt = (double)gvox;
+    double dm = a / cnt;
+    double var = b / cnt - dm * dm;
+    if (var < 0.0) var = 0.0;
+    double m = k + dm;
+    mean[i] = (float)m;
+    invstd[i] = (float)(1.0 / sqrt(var + (double)eps));
+    if (running_mean != nullptr && groups == 1) {
+        double unb = cnt > 1.0 ? var * cnt / (cnt - 1.0) : var;
+        running_mean[c] = (float)((1.0 - momentum) * (double)running_mean[c] + momentum * m);
+        running_var[c] = (float)((1.0 - momentum) * (double)running_var[c] + momentum * unb);
+    }
+}
+
+// ------------------------------------------------------------------ forward apply
+template <int VEC>
+__global__ void __launch_bounds__(256)
+norm_act_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, const float* __restrict__ mean,
+                    const float* __restrict__ invstd, const float* __restrict__ gamma, const float* __restrict__ beta,
+                    const float* __restrict__ alpha, int alpha_n, int act, float slope, int C, int x_ld, int y_ld,
+                    int64_t gvox, int CL, int VT) {
+    const int tid = threadIdx.x;
+    const int cl = tid % CL, vt = tid / CL;
+    const int c0 = (blockIdx.y * CL + cl) * VEC;
+    if (vt >= VT || c0 >= C) return;
+    const int group = blockIdx.z;
+    float sc[VEC], sh[VEC], al[VEC];
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) {
+        int c = c0 + j;
+        float gm = gamma ? gamma[c] : 1.f;
+        float bt = beta ? beta[c] : 0.f;
+        float mu = mean ? mean[group * C + c] : 0.f;
+        float is = invstd ? invstd[group * C + c] : 1.f;
+        sc[j] = gm * is;
+        sh[j] = bt - mu * sc[j];
+        al[j] = (act == MRI3D_ACT_PRELU) ? alpha[alpha_n == 1 ? 0 : c] : slope;
+    }
+    const float* xg = x + (int64_t)group * gvox * x_ld;
+    float* yg = y + (int64_t)group * gvox * y_ld;
+    for (int64_t v = (int64_t)blockIdx.x * VT + vt; v < gvox; v += (int64_t)gridDim.x * VT) {
+        float xv[VEC], yv[VEC];
+        Ld<VEC>::load(xg + v * x_ld + c0, xv);
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) yv[j] = apply_act(fmaf(xv[j], sc[j], sh[j]), act, al[j]);
+        Ld<VEC>::store(yg + v * y_ld + c0, yv);
+    }
+}
+
+// ------------------------------------------------------------------ backward: reductions
+// part[group][blk][c][3] = (sum du, sum du*xhat, sum dy*u*[u<=0])
+template <int VEC>
+__global__ void __launch_bounds__(256)
+norm_act_bwd_reduce_kernel(const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ part,
+                           const float* __restrict__ mean, const float* __restrict__ invstd,
+                           const float* __restrict__ gamma, const float* __restrict__ beta,
+                           const float* __restrict__ alpha, int alpha_n, int act, float slope, int C, int x_ld,
+                           int y_ld, int64_t gvox, int CL, int VT) {
+    __shared__ float red[256 * 3 * VEC];
+    const int tid = threadIdx.x;
+    const int cl = tid % CL, vt = tid / CL;
+    const int c0 = (blockIdx.y * CL + cl) * VEC;
+    const bool active = vt < VT && c0 < C;
+    const int group = blockIdx.z;
+    float s0[VEC], s1[VEC], s2[VEC];
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) { s0[j] = 0.f; s1[j] = 0.f; s2[j] = 0.f; }
+    if (active) {
+        float mu[VEC], is[VEC], gm[VEC], bt[VEC], al[VEC];
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) {
+            int c = c0 + j;
+            gm[j] = gamma ? gamma[c] : 1.f;
+            bt[j] = beta ? beta[c] : 0.f;
+            mu[j] = mean ? mean[group * C + c] : 0.f;
+            is[j] = invstd ? invstd[group * C + c] : 1.f;
+            al[j] = (act == MRI3D_ACT_PRELU) ? alpha[alpha_n == 1 ? 0 : c]
+                                              : (act == MRI3D_ACT_LEAKY ? slope : (act == MRI3D_ACT_RELU ? 0.f : 1.f));
+        }
+        const float* xg = x + (int64_t)group * gvox * x_ld;
+        const float* dg = dy + (int64_t)group * gvox * y_ld;
+        for (int64_t v = (int64_t)blockIdx.x * VT + vt; v < gvox; v += (int64_t)gridDim.x * VT) {
+            float xv[VEC], gv[VEC];
+            Ld<VEC>::load(xg + v * x_ld + c0, xv);
+            Ld<VEC>::load(dg + v * y_ld + c0, gv);
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) {
+                float xh = (xv[j] - mu[j]) * is[j];
+                float u = fmaf(gm[j], xh, bt[j]);
+                bool pos = u > 0.f;
+                float du = pos ? gv[j] : gv[j] * al[j];
+                s0[j] += du;
+                s1[j] = fmaf(du, xh, s1[j]);
+                s2[j] += pos ? 0.f : gv[j] * u;
+            }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) {
+        red[(tid * VEC + j) * 3] = s0[j];
+        red[(tid * VEC + j) * 3 + 1] = s1[j];
+        red[(tid * VEC + j) * 3 + 2] = s2[j];
+    }
+    __syncthreads();
+    if (vt == 0 && c0 < C) {
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) {
+            float a = 0.f, b = 0.f, d = 0.f;
+            for (int q = 0; q < VT; ++q) {
+                a += red[((q * CL + cl) * VEC + j) * 3];
+                b += red[((q * CL + cl) * VEC + j) * 3 + 1];
+                d += red[((q * CL + cl) * VEC + j) * 3 + 2];
+            }
+            float* o = part + (((size_t)group * gridDim.x + blockIdx.x) * C + c0 + j) * 3;
+            o[0] = a;
+            o[1] = b;
+            o[2] = d;
+        }
+    }
+}
+
+// Stage A: sums[group][c][3] = fixed-order double sums of the per-block partials.
+__global__ void __launch_bounds__(256)
+norm_act_bwd_sums_kernel(const float* __restrict__ part, float* __restrict__ sums, int C, int nblk, int groups) {
+    __shared__ double r0[256], r1[256], r2[256];
+    const int slot = threadIdx.x / kFinQL, ql = threadIdx.x % kFinQL;
+    const int i = blockIdx.x * (256 / kFinQL) + slot;
+    const bool ok = i < groups * C;
+    const int group = ok ? i / C : 0, c = ok ? i - group * C : 0;
+    double a = 0.0, b = 0.0, d = 0.0;
+    if (ok) {
+        const float* p = part + ((size_t)group * nblk * C + c) * 3;
+        for (int q = ql; q < nblk; q += kFinQL) {
+            a += (double)p[(size_t)q * C * 3];
+            b += (double)p[(size_t)q * C * 3 + 1];
+            d += (double)p[(size_t)q * C * 3 + 2];
+        }
+    }
+    r0[threadIdx.x] = a;
+    r1[threadIdx.x] = b;
+    r2[threadIdx.x] = d;
+    __syncthreads();
+    if (!ok || ql != 0) return;
+    a = b = d = 0.0;
+    for (int q = 0; q < kFinQL; ++q) {
+        a += r0[slot * kFinQL + q];
+        b += r1[slot * kFinQL + q];
+        d += r2[slot * kFinQL + q];
+    }
+    sums[(size_t)i * 3] = (float)a;
+    sums[(size_t)i * 3 + 1] = (float)b;
+    sums[(size_t)i * 3 + 2] = (float)d;
+}
+
+// Stage B (one block): dbeta/dgamma = sum over groups; dalpha per channel or grand total.
+__global__ void norm_act_bwd_params_kernel(const float* __restrict__ sums, float* __restrict__ dgamma,
+                                           float* __restrict__ dbeta, float* __restrict__ dalpha, int alpha_n, int C,
+                                           int groups) {
+    __shared__ double dal[256];
+    double my_dal = 0.0;
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+        double tg = 0.0, tb = 0.0, ta = 0.0;
+        for (int g = 0; g < groups; ++g) {
+            tb += (double)sums[((size_t)g * C + c) * 3];
+            tg += (double)sums[((size_t)g * C + c) * 3 + 1];
+            ta += (double)sums[((size_t)g * C + c) * 3 + 2];
+        }
+        if (dgamma) dgamma[c] = (float)tg;
+        if (dbeta) dbeta[c] = (float)tb;
+        if (dalpha && alpha_n > 1) dalpha[c] = (float)ta;
+        my_dal += ta;
+    }
+    if (dalpha && alpha_n == 1) {
+        dal[threadIdx.x] = my_dal;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            double t = 0.0;
+            for (int i = 0; i < (int)blockDim.x; ++i) t += dal[i];
+            dalpha[0] = (float)t;
+        }
+    }
+}
+
+// ------------------------------------------------------------------ backward: dx
+template <int VEC>
+__global__ void __launch_bounds__(256)
+norm_act_bwd_apply_kernel(const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ dx,
+                          const float* __restrict__ sums, const float* __restrict__ mean,
+                          const float* __restrict__ invstd, const float* __restrict__ gamma,
+                          const float* __restrict__ beta, const float* __restrict__ alpha, int alpha_n, int act,
+                          float slope, int training, int C, int x_ld, int y_ld, int64_t gvox, int CL, int VT) {
+    const int tid = threadIdx.x;
+    const int cl = tid % CL, vt = tid / CL;
+    const int c0 = (blockIdx.y * CL + cl) * VEC;
+    if (vt >= VT || c0 >= C) return;
+    const int group = blockIdx.z;
+    float mu[VEC], is[VEC], gm[VEC], bt[VEC], al[VEC], k0[VEC], k1[VEC], k2[VEC];
+    const float invM = 1.f / (float)gvox;
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) {
+        int c = c0 + j;
+        gm[j] = gamma ? gamma[c] : 1.f;
+        bt[j] = beta ? beta[c] : 0.f;
+        mu[j] = mean ? mean[group * C + c] : 0.f;
+        is[j] = invstd ? invstd[group * C + c] : 1.f;
+        al[j] = (act == MRI3D_ACT_PRELU) ? alpha[alpha_n == 1 ? 0 : c]
+                                          : (act == MRI3D_ACT_LEAKY ? slope : (act == MRI3D_ACT_RELU ? 0.f : 1.f));
+        // dx = k0*du - k1 - xhat*k2
+        k0[j] = gm[j] * is[j];
+        if (training) {
+            k1[j] = k0[j] * sums[((size_t)group * C + c) * 3] * invM;
+            k2[j] = k0[j] * sums[((size_t)group * C + c) * 3 + 1] * invM;
+        } else {
+            k1[j] = 0.f;
+            k2[j] = 0.f;
+        }
+    }
+    const float* xg = x + (int64_t)group * gvox * x_ld;
+    const float* dg = dy + (int64_t)group * gvox * y_ld;
+    float* og = dx + (int64_t)group * gvox * x_ld;
+    for (int64_t v = (int64_t)blockIdx.x * VT + vt; v < gvox; v += (int64_t)gridDim.x * VT) {
+        float xv[VEC], gv[VEC], ov[VEC];
+        Ld<VEC>::load(xg + v * x_ld + c0, xv);
+        Ld<VEC>::load(dg + v * y_ld + c0, gv);
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) {
+            float xh = (xv[j] - mu[j]) * is[j];
+            float u = fmaf(gm[j], xh, bt[j]);
+            float du = (u > 0.f) ? gv[j] : gv[j] * al[j];
+            ov[j] = fmaf(k0[j], du, -k1[j]) - xh * k2[j];
+        }
+        Ld<VEC>::store(og + v * x_ld + c0, ov);
+    }
+}
+
+}  // namespace mri3d
+
+using namespace mri3d;
+
+extern "C" size_t mri3d_norm_workspace_bytes(const Mri3dNormGeom* g) {
+    if (!g) return 0;
+    return norm_workspace_floats(*g) * sizeof(float);
+}
+
+static int norm_check(const Mri3dNormGeom* g, const char* who) {
+    MRI3D_REQUIRE(g != nullptr, MRI3D_EINVAL, "%s: null geometry", who);
+    MRI3D_REQUIRE(g->dtype == MRI3D_F32, MRI3D_ENOTSUP, "%s: only MRI3D_F32 is implemented", who);
+    MRI3D_REQUIRE(g->n > 0 && g->vox > 0 && g->c > 0 && g->x_ld >= g->c && g->y_ld >= g->c, MRI3D_EINVAL,
+                  "%s: bad geometry n=%d vox=%lld c=%d x_ld=%d y_ld=%d", who, g->n, (long long)g->vox, g->c, g->x_ld,
+                  g->y_ld);
+    MRI3D_REQUIRE(g->act != MRI3D_ACT_PRELU || g->alpha_n == 1 || g->alpha_n == g->c, MRI3D_EINVAL,
+                  "%s: PReLU alpha_n=%d must be 1 or C=%d", who, g->alpha_n, g->c);
+    return MRI3D_OK;
+}
+
+extern "C" int mri3d_norm_stats(const Mri3dNormGeom* g, const void* x, float* mean, float* invstd, float* running_mean,
+                                float* running_var, float momentum, void* workspace, size_t ws_bytes,
+                                mri3d_stream_t stream) {
+    int rc = norm_check(g, "norm_stats");
+    if (rc) return rc;
+    MRI3D_REQUIRE(x && mean && invstd, MRI3D_EINVAL, "norm_stats: null pointer");
+    MRI3D_REQUIRE(workspace && ws_bytes >= mri3d_norm_workspace_bytes(g), MRI3D_EWORKSPACE,
+                  "norm_stats: workspace %zu < %zu", ws_bytes, mri3d_norm_workspace_bytes(g));
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    Mri3dNormGeom gg = *g;
+    gg.y_ld = gg.x_ld;
+    NormPlan p = norm_plan(gg, aligned16(x));
+    float* part = static_cast<float*>(workspace);
+    const float* xf = static_cast<const float*>(x);
+    dim3 grid(p.nblk, p.cy, p.groups);
+    if (p.vec == 4)
+        hipLaunchKernelGGL(norm_stats_kernel<4>, grid, dim3(256), 0, s, xf, part, g->c, g->x_ld, p.gvox, p.CL, p.VT);
+    else
+        hipLaunchKernelGGL(norm_stats_kernel<1>, grid, dim3(256), 0, s, xf, part, g->c, g->x_ld, p.gvox, p.CL, p.VT);
+    int tot = p.groups * g->c;
+    hipLaunchKernelGGL(norm_stats_finalize_kernel, dim3(cdiv(tot, 256 / kFinQL)), dim3(256), 0, s, xf, part, mean, invstd,
+                       running_mean, running_var, momentum, g->eps, g->c, g->x_ld, p.gvox, p.nblk, p.groups);
+    return check_launch("norm_stats");
+}
+
+extern "C" int mri3d_norm_act_fwd(const Mri3dNormGeom* g, const void* x, const float* mean, const float* invstd,
+                                  const float* gamma, const float* beta, const float* alpha, void* y,
+                                  mri3d_stream_t stream) {
+    int rc = norm_check(g, "norm_act_fwd");
+    if (rc) return rc;
+    MRI3D_REQUIRE(x && y, MRI3D_EINVAL, "norm_act_fwd: null pointer");
+    MRI3D_REQUIRE((mean == nullptr) == (invstd == nullptr), MRI3D_EINVAL, "norm_act_fwd: mean/invstd must both be set");
+    MRI3D_REQUIRE(g->act != MRI3D_ACT_PRELU || alpha, MRI3D_EINVAL, "norm_act_fwd: PReLU needs alpha");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    NormPlan p = norm_plan(*g, aligned16(x, y));
+    dim3 grid(p.nblk, p.cy, p.groups);
+    const float* xf = static_cast<const float*>(x);
+    float* yf = static_cast<float*>(y);
+    if (p.vec == 4)
+        hipLaunchKernelGGL(norm_act_fwd_kernel<4>, grid, dim3(256), 0, s, xf, yf, mean, invstd, gamma, beta, alpha,
+                           g->alpha_n, g->act, g->slope, g->c, g->x_ld, g->y_ld, p.gvox, p.CL, p.VT);
+    else
+        hipLaunchKernelGGL(norm_act_fwd_kernel<1>, grid, dim3(256), 0, s, xf, yf, mean, invstd, gamma, beta, alpha,
+                           g->alpha_n, g->act, g->slope, g->c, g->x_ld, g->y_ld, p.gvox, p.CL, p.VT);
+    return check_launch("norm_act_fwd");
+}
+
+extern "C" int mri3d_norm_act_bwd(const Mri3dNormGeom* g, int training, const void* x, const void* dy,
+                                  const float* mean, const float* invstd, const float* gamma, const float* beta,
+                                  const float* alpha, void* dx, float* dgamma, float* dbeta, float* dalpha,
+                                  void* workspace, size_t ws_bytes, mri3d_stream_t stream) {
+    int rc = norm_check(g, "norm_act_bwd");
+    if (rc) return rc;
+    MRI3D_REQUIRE(x && dy && dx, MRI3D_EINVAL, "norm_act_bwd: null pointer");
+    MRI3D_REQUIRE((mean == nullptr) == (invstd == nullptr), MRI3D_EINVAL, "norm_act_bwd: mean/invstd must both be set");
+    MRI3D_REQUIRE(!(training && mean == nullptr), MRI3D_EINVAL, "norm_act_bwd: training mode needs statistics");
+    MRI3D_REQUIRE(g->act != MRI3D_ACT_PRELU || alpha, MRI3D_EINVAL, "norm_act_bwd: PReLU needs alpha");
+    MRI3D_REQUIRE(workspace && ws_bytes >= mri3d_norm_workspace_bytes(g), MRI3D_EWORKSPACE,
+                  "norm_act_bwd: workspace %zu < %zu", ws_bytes, mri3d_norm_workspace_bytes(g));
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    // x/dx share pitch x_ld, dy has pitch y_ld
+    NormPlan p = norm_plan(*g, aligned16(x, dy, dx));
+    dim3 grid(p.nblk, p.cy, p.groups);
+    const float* xf = static_cast<const float*>(x);
+    const float* df = static_cast<const float*>(dy);
+    float* of = static_cast<float*>(dx);
+    float* part = static_cast<float*>(workspace);
+    float* sums = part + (size_t)p.groups * p.nblk * g->c * 3;
+    const bool need_reduce = training || dgamma || dbeta || dalpha;
+    if (need_reduce) {
+        if (p.vec == 4)
+            hipLaunchKernelGGL(norm_act_bwd_reduce_kernel<4>, grid, dim3(256), 0, s, xf, df, part, mean, invstd, gamma,
+                               beta, alpha, g->alpha_n, g->act, g->slope, g->c, g->x_ld, g->y_ld, p.gvox, p.CL, p.VT);
+        else
+            hipLaunchKernelGGL(norm_act_bwd_reduce_kernel<1>, grid, dim3(256), 0, s, xf, df, part, mean, invstd, gamma,
+                               beta, alpha, g->alpha_n, g->act, g->slope, g->c, g->x_ld, g->y_ld, p.gvox, p.CL, p.VT);
+        hipLaunchKernelGGL(norm_act_bwd_sums_kernel, dim3(cdiv(p.groups * g->c, 256 / kFinQL)), dim3(256), 0, s, part,
+                           sums, g->c, p.nblk, p.groups);
+        if (dgamma || dbeta || dalpha)
+            hipLaunchKernelGGL(norm_act_bwd_params_kernel, dim3(1), dim3(256), 0, s, sums, dgamma, dbeta, dalpha,
+                               g->alpha_n, g->c, p.groups);
+    }
+    if (p.vec == 4)
+        hipLaunchKernelGGL(norm_act_bwd_apply_kernel<4>, grid, dim3(256), 0, s, xf, df, of, sums, mean, invstd, gamma,
+                           beta, alpha, g->alpha_n, g->act, g->slope, training, g->c, g->x_ld, g->y_ld, p.gvox, p.CL,
+                           p.VT);
+    else
+        hipLaunchKernelGGL(norm_act_bwd_apply_kernel<1>, grid, dim3(256), 0, s, xf, df, of, sums, mean, invstd, gamma,
+                           beta, alpha, g->alpha_n, g->act, g->slope, training, g->c, g->x_ld, g->y_ld, p.gvox, p.CL,
+                           p.VT);
+    return check_launch("norm_act_bwd");
+}

@@ -1,0 +1,571 @@
+"""Operator seam: one ``torch.autograd.Function`` per volumetric op, each a thin wrapper over the C-ABI HIP library.
+
+Tensors keep torch's logical (N, C, D, H, W) shape but live in channels-last-3d memory (NDHWC), which is what the
+kernels index.  Every op here requires a ROCm device tensor and the built ``libmri3d_hip.so``; there is no CPU or
+eager-PyTorch fallback (a CPU tensor raises), so a green GPU test always means the HIP kernels ran.
+
+Reference operators replaced (file:line in /root/reference):
+  conv3d               nn.Conv3d            unet.UNet via segmentation/routine.py:346-356; AE_model.py:9-26; cnn_model.py:14
+  conv_transpose3d     nn.ConvTranspose3d   AE_model.py:62-68,159
+  norm_act             nn.BatchNorm3d / nn.InstanceNorm3d + PReLU/LeakyReLU/ReLU   AE_model.py:30-36; modified_3dunet.py:20-94
+  max_pool3d           nn.MaxPool3d         AE_model.py:27; cnn_model.py:115-148,221
+  upsample3d           nn.Upsample / F.interpolate   modified_3dunet.py:13; AE_model.py:70-73,119
+  softmax_dice_loss    F.softmax + get_dice_loss + mean   segmentation/routine.py:239-253,272-274
+  cat_channels / add   torch.cat(dim=1) / residual adds   modified_3dunet.py:108,158
+"""
+import ctypes
+import math
+
+import torch
+
+from . import _lib
+from ._lib import (ACT_LEAKY, ACT_NONE, ACT_PRELU, ACT_RELU, F32, PASS_DGRAD, PASS_FWD, PASS_WGRAD, UP_NEAREST,
+                   UP_TRILINEAR, ConvGeom, DiceGeom, NormGeom, PoolGeom, UpGeom, check)
+
+CL3D = torch.channels_last_3d
+
+# ----------------------------------------------------------------------------------------------- plumbing
+
+
+def _require_device(*ts):
+    for t in ts:
+        if t is None:
+            continue
+        if not t.is_cuda:
+            raise RuntimeError(
+                "mri_epilepsy_diagnosis_amd ops run only on a ROCm device tensor (got %s); there is no CPU fallback"
+                % t.device)
+        if t.dtype != torch.float32:
+            raise RuntimeError("mri_epilepsy_diagnosis_amd ops: only float32 tensors are supported, got %s" % t.dtype)
+
+
+def _is_ndhwc_dense(x):
+    n, c, d, h, w = x.shape
+    exp = (d * h * w * c, 1, h * w * c, w * c, c)
+    for dim in range(5):
+        if x.shape[dim] > 1 and x.stride(dim) != exp[dim]:
+            return False
+    return True
+
+
+def _cl(x):
+    """Return x with dense NDHWC memory (no copy if it already is)."""
+    if x.dim() != 5:
+        raise RuntimeError("expected a 5-D (N,C,D,H,W) tensor, got shape %s" % (tuple(x.shape),))
+    if _is_ndhwc_dense(x):
+        return x
+    return x.contiguous(memory_format=CL3D)
+
+
+def _new(shape, like):
+    return torch.empty(shape, dtype=like.dtype, device=like.device, memory_format=CL3D)
+
+
+def _ptr(t, byte_offset=0):
+    if t is None:
+        return None
+    return ctypes.c_void_p(t.data_ptr() + byte_offset)
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+_workspaces = {}
+
+
+def _workspace(nbytes, device):
+    """Grow-only scratch buffer per (device, stream); kernels using it are ordered on that stream."""
+    key = (device.index, torch.cuda.current_stream(device).cuda_stream)
+    ws = _workspaces.get(key)
+    if ws is None or ws.numel() < nbytes:
+        ws = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
+        _workspaces[key] = ws
+    return ws
+
+
+def _triple(v):
+    if isinstance(v, (tuple, list)):
+        if len(v) == 1:
+            return (int(v[0]),) * 3
+        return tuple(int(a) for a in v)
+    return (int(v),) * 3
+
+
+# ----------------------------------------------------------------------------------------------- conv
+
+
+def _conv_geom(xshape, wshape, stride, padding, dilation):
+    n, ci, di, hi, wi = xshape
+    co, ci_w, kd, kh, kw = wshape
+    if ci_w != ci:
+        raise RuntimeError("conv3d: weight expects %d input channels, input has %d (groups are not supported)" % (ci_w, ci))
+    sd, sh, sw = stride
+    pd, ph, pw = padding
+    dd, dh, dw = dilation
+    do = (di + 2 * pd - dd * (kd - 1) - 1) // sd + 1
+    ho = (hi + 2 * ph - dh * (kh - 1) - 1) // sh + 1
+    wo = (wi + 2 * pw - dw * (kw - 1) - 1) // sw + 1
+    if do <= 0 or ho <= 0 or wo <= 0:
+        raise RuntimeError("Kernel size can't be greater than actual input size")
+    return ConvGeom(n, di, hi, wi, ci, do, ho, wo, co, kd, kh, kw, sd, sh, sw, pd, ph, pw, dd, dh, dw, ci, co, F32)
+
+
+def _conv_fwd(g, x, w, b):
+    L = _lib.lib()
+    y = _new((g.n, g.co, g.dout, g.ho, g.wo), x)
+    nb = L.mri3d_conv3d_workspace_bytes(ctypes.byref(g), PASS_FWD)
+    ws = _workspace(nb, x.device)
+    check(L.mri3d_conv3d_fwd(ctypes.byref(g), _ptr(x), _ptr(w), _ptr(b), _ptr(y), _ptr(ws), ws.numel(), _stream()),
+          "conv3d_fwd")
+    return y
+
+
+def _conv_dgrad(g, dy, w, b, like):
+    L = _lib.lib()
+    dx = _new((g.n, g.ci, g.di, g.hi, g.wi), like)
+    nb = L.mri3d_conv3d_workspace_bytes(ctypes.byref(g), PASS_DGRAD)
+    ws = _workspace(nb, dy.device)
+    check(L.mri3d_conv3d_dgrad(ctypes.byref(g), _ptr(dy), _ptr(w), _ptr(b), _ptr(dx), _ptr(ws), ws.numel(), _stream()),
+          "conv3d_dgrad")
+    return dx
+
+
+def _conv_wgrad(g, x, dy, w_like, want_bias):
+    L = _lib.lib()
+    dw = torch.empty_like(w_like, memory_format=torch.contiguous_format)
+    db = torch.empty(g.co, dtype=w_like.dtype, device=w_like.device) if want_bias else None
+    nb = L.mri3d_conv3d_workspace_bytes(ctypes.byref(g), PASS_WGRAD)
+    ws = _workspace(nb, x.device)
+    check(L.mri3d_conv3d_wgrad(ctypes.byref(g), _ptr(x), _ptr(dy), _ptr(dw), _ptr(db), _ptr(ws), ws.numel(), _stream()),
+          "conv3d_wgrad")
+    return dw, db
+
+
+class _Conv3dFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias, stride, padding, dilation):
+        _require_device(x, weight, bias)
+        x = _cl(x)
+        w = weight.contiguous()
+        g = _conv_geom(x.shape, w.shape, stride, padding, dilation)
+        y = _conv_fwd(g, x, w, bias)
+        ctx.save_for_backward(x, w)
+        ctx.geom = g
+        ctx.has_bias = bias is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        g = ctx.geom
+        dy = _cl(dy)
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dx = _conv_dgrad(g, dy, w, None, x)
+        if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
+            dw, db = _conv_wgrad(g, x, dy, w, ctx.has_bias)
+        return dx, dw, db, None, None, None
+
+
+def conv3d(x, weight, bias=None, stride=1, padding=0, dilation=1):
+    return _Conv3dFn.apply(x, weight, bias, _triple(stride), _triple(padding), _triple(dilation))
+
+
+def _channel_sum(t):
+    """sum over (N,D,H,W) per channel with the norm-statistics kernel (mean * count)."""
+    L = _lib.lib()
+    n, c, d, h, w = t.shape
+    g = NormGeom(n, d * h * w, c, c, c, 0, ACT_NONE, 1, 0.0, 0.0, F32)
+    mean = torch.empty(c, dtype=torch.float32, device=t.device)
+    invstd = torch.empty(c, dtype=torch.float32, device=t.device)
+    ws = _workspace(L.mri3d_norm_workspace_bytes(ctypes.byref(g)), t.device)
+    check(L.mri3d_norm_stats(ctypes.byref(g), _ptr(t), _ptr(mean), _ptr(invstd), None, None, 0.0, _ptr(ws), ws.numel(),
+                             _stream()), "norm_stats")
+    return mean * float(n * d * h * w)
+
+
+class _ConvTranspose3dFn(torch.autograd.Function):
+    """y = conv_transpose3d(x, w, b): forward is the data-gradient kernel of the mirrored Conv3d."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, stride, padding, output_padding, dilation):
+        _require_device(x, weight, bias)
+        x = _cl(x)
+        w = weight.contiguous()  # (Cin_t, Cout_t, kd, kh, kw) == conv weight (Co=Cin_t, Ci=Cout_t)
+        n, cin_t, di, hi, wi = x.shape
+        if w.shape[0] != cin_t:
+            raise RuntimeError("conv_transpose3d: weight expects %d input channels, got %d" % (w.shape[0], cin_t))
+        cout_t, kd, kh, kw = w.shape[1], w.shape[2], w.shape[3], w.shape[4]
+        od = (di - 1) * stride[0] - 2 * padding[0] + dilation[0] * (kd - 1) + output_padding[0] + 1
+        oh = (hi - 1) * stride[1] - 2 * padding[1] + dilation[1] * (kh - 1) + output_padding[1] + 1
+        ow = (wi - 1) * stride[2] - 2 * padding[2] + dilation[2] * (kw - 1) + output_padding[2] + 1
+        # mirrored conv: input (n, cout_t, od, oh, ow) -> output (n, cin_t, di, hi, wi)
+        g = _conv_geom((n, cout_t, od, oh, ow), w.shape, stride, padding, dilation)
+        if (g.dout, g.ho, g.wo) != (di, hi, wi):
+            raise RuntimeError("conv_transpose3d: inconsistent output_padding")
+        y = _conv_dgrad(g, x, w, bias, x)
+        ctx.save_for_backward(x, w)
+        ctx.geom = g
+        ctx.has_bias = bias is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        g = ctx.geom
+        dy = _cl(dy)
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dx = _conv_fwd(g, dy, w, None)
+        if ctx.needs_input_grad[1]:
+            dw, _ = _conv_wgrad(g, dy, x, w, False)
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            db = _channel_sum(dy)
+        return dx, dw, db, None, None, None, None
+
+
+def conv_transpose3d(x, weight, bias=None, stride=1, padding=0, output_padding=0, dilation=1):
+    return _ConvTranspose3dFn.apply(x, weight, bias, _triple(stride), _triple(padding), _triple(output_padding),
+                                    _triple(dilation))
+
+
+# ----------------------------------------------------------------------------------------------- norm + activation
+
+_ACT_CODES = {None: ACT_NONE, "none": ACT_NONE, "relu": ACT_RELU, "leaky_relu": ACT_LEAKY, "prelu": ACT_PRELU}
+
+
+class _NormActFn(torch.autograd.Function):
+    """y = act(gamma * (x - mean) / sqrt(var + eps) + beta) with batch, instance, running or no statistics."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, alpha, running_mean, running_var, stats_mode, momentum, eps, act, slope):
+        # stats_mode: "batch" (compute + update running), "instance", "running" (eval BN), "none" (activation only)
+        _require_device(x, gamma, beta, alpha)
+        L = _lib.lib()
+        x = _cl(x)
+        n, c, d, h, w = x.shape
+        act_code = _ACT_CODES[act]
+        alpha_n = alpha.numel() if (act_code == ACT_PRELU) else 1
+        instance = 1 if stats_mode == "instance" else 0
+        g = NormGeom(n, d * h * w, c, c, c, instance, act_code, alpha_n, float(slope), float(eps), F32)
+        mean = invstd = None
+        if stats_mode in ("batch", "instance"):
+            groups = n if instance else 1
+            mean = torch.empty(groups * c, dtype=torch.float32, device=x.device)
+            invstd = torch.empty(groups * c, dtype=torch.float32, device=x.device)
+            ws = _workspace(L.mri3d_norm_workspace_bytes(ctypes.byref(g)), x.device)
+            upd = stats_mode == "batch" and running_mean is not None
+            check(L.mri3d_norm_stats(ctypes.byref(g), _ptr(x), _ptr(mean), _ptr(invstd),
+                                     _ptr(running_mean) if upd else None, _ptr(running_var) if upd else None,
+                                     float(momentum), _ptr(ws), ws.numel(), _stream()), "norm_stats")
+        elif stats_mode == "running":
+            mean = running_mean.detach().to(torch.float32).contiguous()
+            invstd = torch.rsqrt(running_var.detach().to(torch.float32) + eps).contiguous()
+        y = _new(x.shape, x)
+        check(L.mri3d_norm_act_fwd(ctypes.byref(g), _ptr(x), _ptr(mean), _ptr(invstd), _ptr(gamma), _ptr(beta),
+                                   _ptr(alpha) if act_code == ACT_PRELU else None, _ptr(y), _stream()), "norm_act_fwd")
+        ctx.save_for_backward(x, mean, invstd, gamma, beta, alpha)
+        ctx.geom = g
+        ctx.training_stats = stats_mode in ("batch", "instance")
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        L = _lib.lib()
+        x, mean, invstd, gamma, beta, alpha = ctx.saved_tensors
+        g = ctx.geom
+        dy = _cl(dy)
+        dx = _new(x.shape, x)
+        dgamma = torch.empty_like(gamma) if (gamma is not None and ctx.needs_input_grad[1]) else None
+        dbeta = torch.empty_like(beta) if (beta is not None and ctx.needs_input_grad[2]) else None
+        prelu = g.act == ACT_PRELU
+        dalpha = torch.empty_like(alpha) if (prelu and ctx.needs_input_grad[3]) else None
+        ws = _workspace(L.mri3d_norm_workspace_bytes(ctypes.byref(g)), x.device)
+        check(L.mri3d_norm_act_bwd(ctypes.byref(g), 1 if ctx.training_stats else 0, _ptr(x), _ptr(dy), _ptr(mean),
+                                   _ptr(invstd), _ptr(gamma), _ptr(beta), _ptr(alpha) if prelu else None, _ptr(dx),
+                                   _ptr(dgamma), _ptr(dbeta), _ptr(dalpha), _ptr(ws), ws.numel(), _stream()),
+              "norm_act_bwd")
+        return dx, dgamma, dbeta, dalpha, None, None, None, None, None, None, None
+
+
+def norm_act(x, gamma=None, beta=None, alpha=None, running_mean=None, running_var=None, stats_mode="batch",
+             momentum=0.1, eps=1e-5, act=None, slope=0.01):
+    if momentum is None:
+        raise RuntimeError("cumulative moving average (momentum=None) is not supported")
+    return _NormActFn.apply(x, gamma, beta, alpha, running_mean, running_var, stats_mode, momentum, eps, act, slope)
+
+
+def activation(x, act, alpha=None, slope=0.01):
+    return norm_act(x, None, None, alpha, None, None, "none", 0.1, 0.0, act, slope)
+
+
+class _ScaleInstanceFn(torch.autograd.Function):
+    """y[n,c,...] = x[n,c,...] * scale[n,c]  (Dropout3d mask application, modified_3dunet.py:12)."""
+
+    @staticmethod
+    def forward(ctx, x, scale):
+        _require_device(x, scale)
+        L = _lib.lib()
+        x = _cl(x)
+        n, c, d, h, w = x.shape
+        g = NormGeom(n, d * h * w, c, c, c, 1, ACT_NONE, 1, 0.0, 0.0, F32)
+        scale = scale.reshape(n * c).contiguous()
+        zeros = torch.zeros_like(scale)
+        y = _new(x.shape, x)
+        check(L.mri3d_norm_act_fwd(ctypes.byref(g), _ptr(x), _ptr(zeros), _ptr(scale), None, None, None, _ptr(y),
+                                   _stream()), "norm_act_fwd")
+        ctx.save_for_backward(scale, zeros)
+        ctx.geom = g
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        L = _lib.lib()
+        scale, zeros = ctx.saved_tensors
+        g = ctx.geom
+        dy = _cl(dy)
+        dx = _new(dy.shape, dy)
+        check(L.mri3d_norm_act_fwd(ctypes.byref(g), _ptr(dy), _ptr(zeros), _ptr(scale), None, None, None, _ptr(dx),
+                                   _stream()), "norm_act_fwd")
+        return dx, None
+
+
+def dropout3d(x, p, training):
+    """Channel dropout: the Bernoulli mask is N*C numbers drawn by torch's generator; the volume pass is HIP."""
+    if not training or p == 0.0:
+        return x
+    n, c = x.shape[0], x.shape[1]
+    keep = torch.empty(n, c, device=x.device, dtype=torch.float32).bernoulli_(1.0 - p)
+    return _ScaleInstanceFn.apply(x, keep / (1.0 - p))
+
+
+# ----------------------------------------------------------------------------------------------- pooling
+
+
+def _pool_out(i, k, s, p, ceil_mode):
+    if ceil_mode:
+        o = -(-(i + 2 * p - k) // s) + 1
+        if (o - 1) * s >= i + p:
+            o -= 1
+        return o
+    return (i + 2 * p - k) // s + 1
+
+
+class _MaxPool3dFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, kernel, stride, padding):
+        _require_device(x)
+        L = _lib.lib()
+        x = _cl(x)
+        n, c, d, h, w = x.shape
+        do, ho, wo = (_pool_out(i, k, s, p, False) for i, k, s, p in zip((d, h, w), kernel, stride, padding))
+        if do <= 0 or ho <= 0 or wo <= 0:
+            raise RuntimeError("max_pool3d: output size is too small (input %s, kernel %s)" % ((d, h, w), kernel))
+        g = PoolGeom(n, d, h, w, do, ho, wo, c, *kernel, *stride, *padding, c, c, F32)
+        y = _new((n, c, do, ho, wo), x)
+        idx = torch.empty(n * do * ho * wo * c, dtype=torch.uint8, device=x.device)
+        check(L.mri3d_maxpool3d_fwd(ctypes.byref(g), _ptr(x), _ptr(y), _ptr(idx), _stream()), "maxpool3d_fwd")
+        ctx.save_for_backward(idx)
+        ctx.geom = g
+        ctx.xshape = tuple(x.shape)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        L = _lib.lib()
+        (idx,) = ctx.saved_tensors
+        dy = _cl(dy)
+        dx = _new(ctx.xshape, dy)
+        check(L.mri3d_maxpool3d_bwd(ctypes.byref(ctx.geom), _ptr(dy), _ptr(idx), _ptr(dx), _stream()), "maxpool3d_bwd")
+        return dx, None, None, None
+
+
+def max_pool3d(x, kernel_size, stride=None, padding=0):
+    k = _triple(kernel_size)
+    s = _triple(stride) if stride is not None else k
+    return _MaxPool3dFn.apply(x, k, s, _triple(padding))
+
+
+# ----------------------------------------------------------------------------------------------- upsample
+
+
+class _Upsample3dFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, out_size, mode, align_corners, ratios):
+        _require_device(x)
+        L = _lib.lib()
+        x = _cl(x)
+        n, c, d, h, w = x.shape
+        do, ho, wo = out_size
+        g = UpGeom(n, d, h, w, do, ho, wo, c, c, c, mode, 1 if align_corners else 0, ratios[0], ratios[1], ratios[2], F32)
+        y = _new((n, c, do, ho, wo), x)
+        check(L.mri3d_upsample3d_fwd(ctypes.byref(g), _ptr(x), _ptr(y), _stream()), "upsample3d_fwd")
+        ctx.geom = g
+        ctx.xshape = tuple(x.shape)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        L = _lib.lib()
+        g = ctx.geom
+        dy = _cl(dy)
+        dx = _new(ctx.xshape, dy)
+        ws = _workspace(L.mri3d_upsample3d_workspace_bytes(ctypes.byref(g)), dy.device)
+        check(L.mri3d_upsample3d_bwd(ctypes.byref(g), _ptr(dy), _ptr(dx), _ptr(ws), ws.numel(), _stream()),
+              "upsample3d_bwd")
+        return dx, None, None, None, None
+
+
+def upsample3d(x, size=None, scale_factor=None, mode="nearest", align_corners=None):
+    """torch.nn.functional.interpolate semantics for 5-D input, modes 'nearest' and 'trilinear'."""
+    if mode == "linear":
+        mode = "trilinear"
+    if mode not in ("nearest", "trilinear"):
+        raise NotImplementedError("upsample3d: mode %r is not supported" % (mode,))
+    if mode == "nearest" and align_corners is not None:
+        raise ValueError("align_corners option can only be set with the interpolating modes")
+    in_sz = tuple(x.shape[2:])
+    if (size is None) == (scale_factor is None):
+        raise ValueError("exactly one of size or scale_factor must be given")
+    if size is not None:
+        out = _triple(size)
+        sf = None
+    else:
+        sf = tuple(float(s) for s in (scale_factor if isinstance(scale_factor, (tuple, list)) else (scale_factor,) * 3))
+        out = tuple(int(math.floor(float(i) * s)) for i, s in zip(in_sz, sf))
+    ac = bool(align_corners)
+    ratios = []
+    for a in range(3):
+        i, o = in_sz[a], out[a]
+        if mode == "trilinear" and ac:
+            r = (i - 1) / (o - 1) if o > 1 else 0.0
+        elif sf is not None:
+            r = 1.0 / sf[a]          # torch uses the user-supplied scale when recompute_scale_factor is unset
+        else:
+            r = i / o
+        ratios.append(float(r))
+    code = UP_NEAREST if mode == "nearest" else UP_TRILINEAR
+    return _Upsample3dFn.apply(x, out, code, ac, tuple(ratios))
+
+
+# ----------------------------------------------------------------------------------------------- loss
+
+
+class _SoftmaxDiceFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, logits, target, eps):
+        _require_device(logits, target)
+        L = _lib.lib()
+        logits = _cl(logits)
+        target = _cl(target)
+        n, c, d, h, w = logits.shape
+        ct = target.shape[1]
+        if tuple(target.shape) != (n, ct, d, h, w) or ct not in (1, c):
+            raise RuntimeError("softmax_dice_loss: target shape %s incompatible with logits %s"
+                               % (tuple(target.shape), tuple(logits.shape)))
+        g = DiceGeom(n, d * h * w, c, ct, c, ct, float(eps), F32)
+        loss = torch.empty((), dtype=torch.float32, device=logits.device)
+        stats = torch.empty(n * c * 3, dtype=torch.float32, device=logits.device)
+        ws = _workspace(L.mri3d_softmax_dice_workspace_bytes(ctypes.byref(g)), logits.device)
+        check(L.mri3d_softmax_dice_fwd(ctypes.byref(g), _ptr(logits), _ptr(target), _ptr(loss), _ptr(stats), _ptr(ws),
+                                       ws.numel(), _stream()), "softmax_dice_fwd")
+        ctx.save_for_backward(logits, target, stats)
+        ctx.geom = g
+        return loss
+
+    @staticmethod
+    def backward(ctx, dloss):
+        L = _lib.lib()
+        logits, target, stats = ctx.saved_tensors
+        dloss = dloss.to(torch.float32).contiguous()
+        dlogits = _new(logits.shape, logits)
+        check(L.mri3d_softmax_dice_bwd(ctypes.byref(ctx.geom), _ptr(logits), _ptr(target), _ptr(stats), _ptr(dloss),
+                                       _ptr(dlogits), _stream()), "softmax_dice_bwd")
+        return dlogits, None, None
+
+
+def softmax_dice_loss(logits, target, eps=1e-9):
+    """mean over (n, c) of 1 - dice(softmax(logits)[:, c], target) — segmentation/routine.py:272-274 in one kernel."""
+    return _SoftmaxDiceFn.apply(logits, target.to(torch.float32), eps)
+
+
+def argmax_mask(logits):
+    """logits.argmax(dim=1) as a uint8 (N, D, H, W) mask — segmentation/routine.py:226-227."""
+    _require_device(logits)
+    L = _lib.lib()
+    logits = _cl(logits.detach())
+    n, c, d, h, w = logits.shape
+    out = torch.empty((n, d, h, w), dtype=torch.uint8, device=logits.device)
+    check(L.mri3d_argmax_u8(_ptr(logits), _ptr(out), n * d * h * w, c, c, F32, _stream()), "argmax_u8")
+    return out
+
+
+# ----------------------------------------------------------------------------------------------- cat / add
+
+
+class _CatFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, *xs):
+        _require_device(*xs)
+        L = _lib.lib()
+        xs = [_cl(x) for x in xs]
+        n, _, d, h, w = xs[0].shape
+        for x in xs:
+            if (x.shape[0], x.shape[2], x.shape[3], x.shape[4]) != (n, d, h, w):
+                raise RuntimeError("cat_channels: spatial/batch sizes differ: %s" % [tuple(t.shape) for t in xs])
+        ctot = sum(x.shape[1] for x in xs)
+        y = _new((n, ctot, d, h, w), xs[0])
+        off = 0
+        for x in xs:
+            c = x.shape[1]
+            check(L.mri3d_copy_channels(_ptr(x), _ptr(y, off * 4), n * d * h * w, c, c, ctot, F32, _stream()),
+                  "copy_channels")
+            off += c
+        ctx.chans = [x.shape[1] for x in xs]
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        L = _lib.lib()
+        dy = _cl(dy)
+        n, ctot, d, h, w = dy.shape
+        outs = []
+        off = 0
+        for i, c in enumerate(ctx.chans):
+            if ctx.needs_input_grad[i]:
+                dx = _new((n, c, d, h, w), dy)
+                check(L.mri3d_copy_channels(_ptr(dy, off * 4), _ptr(dx), n * d * h * w, c, ctot, c, F32, _stream()),
+                      "copy_channels")
+                outs.append(dx)
+            else:
+                outs.append(None)
+            off += c
+        return tuple(outs)
+
+
+def cat_channels(xs):
+    return _CatFn.apply(*xs)
+
+
+class _AddFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, a, b):
+        _require_device(a, b)
+        L = _lib.lib()
+        a = _cl(a)
+        b = _cl(b)
+        if a.shape != b.shape:
+            raise RuntimeError("add: shapes differ %s vs %s" % (tuple(a.shape), tuple(b.shape)))
+        n, c, d, h, w = a.shape
+        y = _new(a.shape, a)
+        check(L.mri3d_add_channels(_ptr(a), _ptr(b), _ptr(y), n * d * h * w, c, c, c, c, F32, _stream()), "add_channels")
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        return dy, dy
+
+
+def add(a, b):
+    return _AddFn.apply(a, b)

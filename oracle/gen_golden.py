@@ -1,0 +1,220 @@
+"""Generate tests/golden/* — run ONLY in the authoring container, where /root/reference exists.
+
+    python -m oracle.gen_golden
+
+For every reference module that is importable here (classification/models/AE_model.py, cnn_model.py,
+segmentation/models/modified_3dunet.py) this script
+  1. builds the REFERENCE module and the oracle restatement from the same seed and asserts identical state_dicts,
+  2. runs the REFERENCE module on seeded inputs (forward, loss, backward) and records the results,
+  3. asserts the oracle restatement reproduces them exactly,
+and writes small .npz fixtures (strided output samples, loss, per-parameter gradient norms).  The shipped
+checkpoints used by the parity sub-runs are copied verbatim as data fixtures.  For `unet.UNet` (third-party, source
+absent) the recorded vectors come from oracle.unet_recon with the shipped checkpoint loaded strictly — "parity
+unpinned" with respect to the upstream package, see oracle/__init__.py.
+
+Inputs are never stored: they are regenerated from (seed, shape) with torch's CPU generator, which is
+deterministic for a fixed torch build (the GPU box runs the same image).
+"""
+import hashlib
+import os
+import shutil
+import sys
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+REF = "/root/reference"
+OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
+
+AE_KWARGS_93_6_4 = dict(  # classification/train_ENC_CLF.ipynb cell 17
+    c_in=1, is_skip=False, deapth=3, c_base=8, inc_size=2, reduce_size=False,
+    down_block_kwargs=dict(conv_k=6, conv_pad=2, conv_s=2, maxpool_k=2, maxpool_s=2, batch_norm=True, act="l_relu"),
+    up_block_kwargs=dict(up="upsample", scale=4, scale_mode="nearest", conv_k=3, conv_pad=1, conv_s=1, batch_norm=False,
+                         act="l_relu"))
+DISC_KWARGS = dict(c_in=32, c_out=64, conv_k=3, conv_s=1, conv_pad=0, l_in=64, l_out=32, batch_norm=True, act="relu",
+                   n_domains=18, p_drop=0.5)
+CLF_KWARGS = dict(c_in=32, c_out=64, conv_k=3, conv_s=1, conv_pad=0, l_in=64, l_out=32, batch_norm=True, act="relu",
+                  p_drop=0.5, n_class=2)
+
+
+def seeded_randn(seed, shape):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(*shape, generator=g)
+
+
+def seeded_rand(seed, shape):
+    g = torch.Generator().manual_seed(seed)
+    return torch.rand(*shape, generator=g)
+
+
+def sample(t, n=4096):
+    f = t.detach().reshape(-1)
+    stride = max(1, f.numel() // n)
+    return f[::stride].numpy().copy(), stride
+
+
+def stats(t):
+    t = t.detach().double()
+    return np.array([t.mean().item(), t.abs().mean().item(), t.std().item() if t.numel() > 1 else 0.0, t.numel()])
+
+
+def grad_norms(model):
+    return np.array([p.grad.detach().double().norm().item() if p.grad is not None else -1.0
+                     for _, p in model.named_parameters()])
+
+
+def param_checksum(model):
+    return np.array([p.detach().double().sum().item() for p in model.state_dict().values() if p.dtype.is_floating_point])
+
+
+def assert_same_state(a, b):
+    sa, sb = a.state_dict(), b.state_dict()
+    assert list(sa.keys()) == list(sb.keys())
+    for k in sa:
+        assert torch.equal(sa[k], sb[k]), k
+
+
+def record(ref, orc, x, loss_fn, train, extra=None):
+    """Run reference and oracle identically; return the reference's numbers after asserting equality."""
+    res = []
+    for m in (ref, orc):
+        m.train(train)
+        m.zero_grad(set_to_none=True)
+        out = m(x)
+        out0 = out[0] if isinstance(out, tuple) else out
+        loss = loss_fn(out0)
+        loss.backward()
+        res.append((out0.detach(), loss.detach(), grad_norms(m)))
+    (o_r, l_r, g_r), (o_o, l_o, g_o) = res
+    assert torch.equal(o_r, o_o), (o_r - o_o).abs().max()
+    assert torch.equal(l_r, l_o)
+    assert np.array_equal(g_r, g_o)
+    smp, stride = sample(o_r)
+    d = dict(out_sample=smp, out_stride=np.array(stride), out_stats=stats(o_r), out_shape=np.array(o_r.shape),
+             loss=np.array(l_r.item()), grad_norms=g_r, param_checksum=param_checksum(ref))
+    if extra:
+        d.update(extra)
+    return d
+
+
+def main():
+    sys.path.insert(0, os.path.join(REF, "classification", "models"))
+    sys.path.insert(0, os.path.join(REF, "segmentation", "models"))
+    import AE_model as R_AE          # noqa: E402  (reference, importable here)
+    import cnn_model as R_CNN        # noqa: E402
+    import modified_3dunet as R_M    # noqa: E402
+    sys.path.insert(0, os.path.dirname(OUT.rstrip("/").rsplit("/tests", 1)[0]))
+    from oracle import ae_model as O_AE, cnn_model as O_CNN, modified_3dunet as O_M, unet_recon, losses
+
+    os.makedirs(os.path.join(OUT, "ckpt"), exist_ok=True)
+    torch.set_num_threads(8)
+
+    # ---------------------------------------------------------------- Modified3DUNet (eval: no dropout)
+    torch.manual_seed(0); ref = R_M.Modified3DUNet(1, 2, 8)
+    torch.manual_seed(0); orc = O_M.Modified3DUNet(1, 2, 8)
+    assert_same_state(ref, orc)
+    x = seeded_randn(11, (1, 1, 32, 32, 32))
+    tgt = (seeded_rand(12, (1, 1, 32, 32, 32)) < 0.2).float()
+    np.savez(os.path.join(OUT, "modified3dunet_b8_32.npz"),
+             **record(ref, orc, x, lambda o: losses.softmax_dice_loss(o, tgt), train=False))
+    print("modified3dunet ok")
+
+    # ---------------------------------------------------------------- CNN / VoxResNet / DilatedCNN (train mode: batch stats)
+    for name, cls, kw, shape in (
+            ("cnn_32", "CNN", dict(input_shape=(32, 32, 32), n_filters=16, n_blocks=3), (4, 1, 32, 32, 32)),
+            ("voxresnet_32", "VoxResNet", dict(input_shape=(32, 32, 32), n_filters=8, n_blocks=3), (3, 1, 32, 32, 32)),
+            ("dilatedcnn_180", "DilatedCNN", dict(input_shape=(180, 180, 180), n_channels=2), (2, 1, 180, 180, 180))):
+        torch.manual_seed(0); ref = getattr(R_CNN, cls)(**kw)
+        torch.manual_seed(0); orc = getattr(O_CNN, cls)(**kw)
+        assert_same_state(ref, orc)
+        x = seeded_randn(21, shape)
+        y = torch.arange(shape[0]) % 2
+        lf = (lambda o: F.cross_entropy(o[:, :2], y))
+        np.savez(os.path.join(OUT, name + ".npz"), **record(ref, orc, x, lf, train=True))
+        print(name, "ok")
+
+    # ---------------------------------------------------------------- AE (93_6_4 kwargs) full reconstruction step @64^3
+    torch.manual_seed(0); ref = R_AE.AE(**AE_KWARGS_93_6_4)
+    torch.manual_seed(0); orc = O_AE.AE(**AE_KWARGS_93_6_4)
+    assert_same_state(ref, orc)
+    x = seeded_randn(31, (2, 1, 64, 64, 64))
+    np.savez(os.path.join(OUT, "ae_93_6_4_64.npz"), **record(ref, orc, x, lambda o: F.mse_loss(o, x), train=True))
+    # odd size: exercises the F.interpolate(size=) fix-up of UpBlock (AE_model.py:116-119)
+    x = seeded_randn(32, (2, 1, 72, 80, 68))
+    np.savez(os.path.join(OUT, "ae_93_6_4_odd.npz"), **record(ref, orc, x, lambda o: F.mse_loss(o, x), train=True))
+    print("ae ok")
+
+    # ---------------------------------------------------------------- encoder + clf + disc with the shipped checkpoints @192^3 (eval)
+    for f in ("encoder_93_6_4.pth", "clf_93_6_4.pth", "disc_93_6_4.pth"):
+        shutil.copyfile(os.path.join(REF, "classification", f), os.path.join(OUT, "ckpt", f))
+    out = {}
+    for tag, mod in (("ref", R_AE), ("orc", O_AE)):
+        enc = mod.AE(**AE_KWARGS_93_6_4).enc
+        clf = mod.Classificator(**CLF_KWARGS)
+        disc = mod.Discriminator(**DISC_KWARGS)
+        enc.load_state_dict(torch.load(os.path.join(OUT, "ckpt", "encoder_93_6_4.pth"), weights_only=True, map_location="cpu"))
+        clf.load_state_dict(torch.load(os.path.join(OUT, "ckpt", "clf_93_6_4.pth"), weights_only=True, map_location="cpu"))
+        disc.load_state_dict(torch.load(os.path.join(OUT, "ckpt", "disc_93_6_4.pth"), weights_only=True, map_location="cpu"))
+        enc.eval(); clf.eval(); disc.eval()
+        x = seeded_randn(41, (1, 1, 192, 192, 192))
+        with torch.no_grad():
+            lat, sizes = enc(x)
+            out[tag] = (lat, clf(lat), disc(lat), sizes)
+    for a, b in zip(out["ref"][:3], out["orc"][:3]):
+        assert torch.equal(a, b)
+    assert out["ref"][3] == out["orc"][3]
+    np.savez(os.path.join(OUT, "enc_clf_disc_ckpt_192.npz"), latent=out["ref"][0].numpy(), clf=out["ref"][1].numpy(),
+             disc=out["ref"][2].numpy(), sizes=np.array(out["ref"][3]))
+    print("enc/clf/disc ckpt ok", out["ref"][1])
+
+    # ---------------------------------------------------------------- adversarial losses (train_ENC_CLF.ipynb cell 14) known answers
+    lg = seeded_randn(51, (5, 18)); dom = torch.tensor([0, 3, 17, 4, 4])
+    np.savez(os.path.join(OUT, "adv_loss.npz"), logits=lg.numpy(), domain=dom.numpy(),
+             adv=np.array(losses.adv_loss(dom, lg, 18).item()))
+
+    # ---------------------------------------------------------------- dice known answers (seed-0 vector) + reference function text-free check
+    torch.manual_seed(0)
+    lg = torch.randn(1, 2, 8, 8, 8); tg = (torch.rand(1, 1, 8, 8, 8) > 0.7).float()
+    per = 1 - losses.dice_score(F.softmax(lg, dim=1), tg)
+    np.savez(os.path.join(OUT, "dice_known.npz"), logits=lg.numpy(), target=tg.numpy(), per_channel=per.numpy(),
+             loss=np.array(per.mean().item()))
+    print("dice known", per, per.mean().item())
+
+    # ---------------------------------------------------------------- unet.UNet (third-party): oracle + shipped checkpoint
+    ck = "whole_im_train_seg_parc_epoch_7.pth"
+    shutil.copyfile(os.path.join(REF, "segmentation", "weights", ck), os.path.join(OUT, "ckpt", ck))
+    m = unet_recon.UNetRecon(out_channels_first_layer=8)
+    print(m.load_state_dict(torch.load(os.path.join(OUT, "ckpt", ck), weights_only=True, map_location="cpu"), strict=True))
+    x = seeded_randn(61, (1, 1, 32, 32, 32))
+    tgt = (seeded_rand(62, (1, 1, 32, 32, 32)) < 0.1).float()
+    m.eval()
+    with torch.no_grad():
+        lo = m(x)
+    mask = lo.argmax(dim=1).to(torch.uint8).numpy()
+    d = dict(eval_sample=sample(lo)[0], eval_stride=np.array(sample(lo)[1]), eval_stats=stats(lo),
+             mask_sha256=np.array(hashlib.sha256(mask.tobytes()).hexdigest()), mask_sum=np.array(int(mask.sum())))
+    m.train(); m.zero_grad()
+    lo = m(x)
+    loss = losses.softmax_dice_loss(lo, tgt)
+    loss.backward()
+    d.update(train_sample=sample(lo)[0], train_stats=stats(lo), loss=np.array(loss.item()), grad_norms=grad_norms(m),
+             running_mean_b0c2=m.encoder.encoding_blocks[0].conv2.norm_layer.running_mean.numpy().copy(),
+             running_var_b0c2=m.encoder.encoding_blocks[0].conv2.norm_layer.running_var.numpy().copy())
+    np.savez(os.path.join(OUT, "unet_c8_ckpt_32.npz"), **d)
+    # seeded 2-iteration loss trajectory: fresh c0=8 model, AdamW defaults, batch 1 @32^3
+    torch.manual_seed(0)
+    m = unet_recon.UNetRecon(out_channels_first_layer=8)
+    opt = torch.optim.AdamW(m.parameters())
+    traj = []
+    for it in range(3):
+        x = seeded_randn(70 + it, (1, 1, 32, 32, 32)); tgt = (seeded_rand(80 + it, (1, 1, 32, 32, 32)) < 0.1).float()
+        opt.zero_grad()
+        loss = losses.softmax_dice_loss(m(x), tgt)
+        loss.backward(); opt.step(); traj.append(loss.item())
+    np.savez(os.path.join(OUT, "unet_c8_traj_32.npz"), losses=np.array(traj), param_checksum=param_checksum(m))
+    print("unet ok", traj)
+
+
+if __name__ == "__main__":
+    main()
