@@ -1,0 +1,185 @@
+#!/usr/bin/env python3
+"""bench.py — MRI volumes/sec (fwd + bwd + optimizer step) of the 3-D U-Net at 160x192x160 on N MI355X GPUs.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+Workload (BASELINE.json configs[1], the configuration the metric is quoted on): `unet.UNet`(c0=8, 3 encoding blocks,
+BatchNorm + PReLU, trilinear upsampling) on a batch of 2 synthetic z-normalised-T1-like fp32 volumes of
+1x160x192x160 per GPU, soft-Dice loss against a Bernoulli(0.1) mask, AdamW.  One step = forward + softmax-Dice +
+backward + (flat-gradient RCCL all-reduce when N > 1) + fused AdamW on every rank (weak scaling: 2 volumes per GPU).
+Inputs are generated on the device before the timed region.
+
+Prints ONE JSON line on rank 0 (see the driver contract), including
+  roofline     — the dominant kernel (largest share of step time) measured live with stream events inside the timed
+                 region: algorithmic FLOP (or bytes) per launch / average launch time against the gfx950 peak;
+  cpu_baseline — the CPU oracle (PyTorch restatement of the reference model, kind "port") timed on this box's host
+                 cores on a bounded sample (batch-1 volumes of the same size), rank 0, N == 1 only.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+PEAK_F32_TFLOPS = 157.3  # MI355X dense fp32 (vector == fp32-input MFMA), MI355X_MICROARCH.md
+PEAK_HBM_GBS = 8000.0    # HBM3E spec
+SHAPE = (160, 192, 160)
+PER_GPU_BATCH = 2
+C0 = 8
+
+
+def build_model(device):
+    from mri_epilepsy_diagnosis_amd.unet import UNet
+    torch.manual_seed(0)
+    return UNet(in_channels=1, out_classes=2, dimensions=3, num_encoding_blocks=3, out_channels_first_layer=C0,
+                normalization="batch", upsampling_type="linear", padding=True, activation="PReLU").to(device)
+
+
+def cpu_baseline(max_seconds=30.0):
+    """Oracle (CPU restatement of the reference model) fwd+bwd+AdamW on batch-1 volumes of the bench size."""
+    from oracle import losses, unet_recon
+    torch.manual_seed(0)
+    threads = os.cpu_count() or 1
+    torch.set_num_threads(threads)
+    m = unet_recon.UNetRecon(out_channels_first_layer=C0)
+    opt = torch.optim.AdamW(m.parameters())
+    g = torch.Generator().manual_seed(1234)
+    x = torch.randn(1, 1, *SHAPE, generator=g)
+    t = (torch.rand(1, 1, *SHAPE, generator=g) < 0.1).float()
+    times = []
+    t_start = time.perf_counter()
+    for it in range(4):
+        t0 = time.perf_counter()
+        opt.zero_grad()
+        loss = losses.softmax_dice_loss(m(x), t)
+        loss.backward()
+        opt.step()
+        dt = time.perf_counter() - t0
+        if it > 0:
+            times.append(dt)
+        if time.perf_counter() - t_start > max_seconds and times:
+            break
+    if not times:
+        times = [dt]
+    sec = sum(times) / len(times)
+    return {"value": 1.0 / sec, "unit": "volumes/s", "cores": threads, "kind": "port",
+            "sample": "%d timed fwd+bwd+AdamW iterations (after 1 warm-up) of the CPU oracle UNetRecon(c0=%d) on 1 volume "
+                      "of 1x%dx%dx%d fp32, torch %s, %d threads" % (len(times), C0, *SHAPE, torch.__version__, threads)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    from mri_epilepsy_diagnosis_amd import _lib, ops, parallel
+    if not os.path.exists(_lib.LIB_PATH):
+        raise SystemExit("libmri3d_hip.so is missing — run `python __graft_entry__.py` first (no fallback path exists)")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a ROCm device")
+
+    rank, local, world = parallel.init_from_env("nccl")
+    if world != args.gpus and world > 1:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    device = torch.device("cuda", local)
+    torch.cuda.set_device(device)
+
+    model = build_model(device)
+    flat = parallel.FlatParams(model)
+    opt = parallel.FlatAdam(flat, lr=1e-3, weight_decay=1e-2, decoupled=True)  # torch.optim.AdamW defaults
+    g = torch.Generator(device=device).manual_seed(1234 + rank)
+    x = torch.randn(PER_GPU_BATCH, 1, *SHAPE, device=device, generator=g)
+    t = (torch.rand(PER_GPU_BATCH, 1, *SHAPE, device=device, generator=g) < 0.1).float()
+    model.train()
+
+    def step():
+        opt.zero_grad()
+        loss = ops.softmax_dice_loss(model(x), t)
+        loss.backward()
+        opt.step(flat.all_reduce())
+        return loss
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    timer = ops.KernelTimer() if rank == 0 else None
+    ops.set_timer(timer)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    ops.set_timer(None)
+    if world > 1:
+        tt = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
+        elapsed = tt.item()
+    final_loss = loss.item()
+
+    if rank == 0:
+        agg = timer.summary()
+        total_ms = sum(a["ms"] for a in agg.values())
+        dom_tag, dom = max(agg.items(), key=lambda kv: kv[1]["ms"])
+        avg_s = dom["ms"] / dom["calls"] / 1e3
+        work = dom["work"] or {"flops": 0.0, "bytes": 0.0}
+        ai = work["flops"] / max(work["bytes"], 1.0)
+        if ai > PEAK_F32_TFLOPS * 1e12 / (PEAK_HBM_GBS * 1e9):
+            achieved, peak, unit, bound = work["flops"] / avg_s / 1e12, PEAK_F32_TFLOPS, "TFLOP/s", "mfma"
+        else:
+            achieved, peak, unit, bound = work["bytes"] / avg_s / 1e9, PEAK_HBM_GBS, "GB/s", "hbm"
+        roofline = {"bound": bound, "achieved": round(achieved, 3), "peak": peak, "unit": unit,
+                    "frac": round(achieved / peak, 4), "traffic": None, "kernel": dom_tag,
+                    "avg_launch_ms": round(avg_s * 1e3, 4), "share_of_timed_ops": round(dom["ms"] / total_ms, 4)}
+        top = sorted(agg.items(), key=lambda kv: -kv[1]["ms"])[:12]
+        sys.stderr.write("per-operator device time over %d steps (events on the launch stream):\n" % args.steps)
+        for tag, a in top:
+            w = a["work"] or {}
+            tf = (w.get("flops", 0) * a["calls"] / (a["ms"] / 1e3) / 1e12) if a["ms"] > 0 else 0
+            gb = (w.get("bytes", 0) * a["calls"] / (a["ms"] / 1e3) / 1e9) if a["ms"] > 0 else 0
+            sys.stderr.write("  %8.2f ms %5.1f%%  %7.2f TF/s %8.1f GB/s  x%-4d %s\n"
+                             % (a["ms"], 100 * a["ms"] / total_ms, tf, gb, a["calls"], tag))
+        sys.stderr.write("  timed ops cover %.1f ms of %.1f ms wall\n" % (total_ms, elapsed * 1e3))
+        out = {
+            "metric": "MRI volumes/sec (fwd+bwd) 3D U-Net @160x192x160",
+            "value": round(world * PER_GPU_BATCH * args.steps / elapsed, 4),
+            "unit": "volumes/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 3),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": "unet.UNet(c0=8, 3 enc blocks, BN+PReLU, trilinear) fwd+softmax-Dice+bwd+AdamW, "
+                                   "batch 2 x 1x160x192x160 fp32 per GPU (BASELINE configs[1])",
+                       "global_batch": world * PER_GPU_BATCH, "volume": list(SHAPE),
+                       "parallelism": "dp%d" % world, "final_loss": round(final_loss, 6)},
+            "roofline": roofline,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

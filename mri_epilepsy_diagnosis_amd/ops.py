@@ -84,6 +84,63 @@ def _workspace(nbytes, device):
     return ws
 
 
+class KernelTimer:
+    """Optional per-operator device timing: when installed (bench.py), every C-ABI call made through `_timed` is
+    bracketed by two events recorded on the stream the kernels are enqueued on (torch's current stream)."""
+
+    def __init__(self):
+        self.records = []  # (tag, work, start_event, end_event)
+
+    def summary(self):
+        torch.cuda.synchronize()
+        agg = {}
+        for tag, work, e0, e1 in self.records:
+            a = agg.setdefault(tag, {"ms": 0.0, "calls": 0, "work": work})
+            a["ms"] += e0.elapsed_time(e1)
+            a["calls"] += 1
+        return agg
+
+
+_timer = None
+
+
+def set_timer(t):
+    global _timer
+    _timer = t
+
+
+class _timed:
+    """with _timed(tag, work): <C-ABI call>  — `work` = dict(flops=..., bytes=...) algorithmic figures per call."""
+
+    def __init__(self, tag, work=None):
+        self.tag, self.work = tag, work
+
+    def __enter__(self):
+        if _timer is not None:
+            self.e0 = torch.cuda.Event(enable_timing=True)
+            self.e0.record()
+
+    def __exit__(self, *exc):
+        if _timer is not None:
+            e1 = torch.cuda.Event(enable_timing=True)
+            e1.record()
+            _timer.records.append((self.tag, self.work, self.e0, e1))
+        return False
+
+
+def _conv_tag(kind, g):
+    return "conv3d_%s %dx%dx%d s%d d%d %d->%d @%dx%dx%d n%d" % (kind, g.kd, g.kh, g.kw, g.sd * g.sh * g.sw,
+                                                             g.dd * g.dh * g.dw, g.ci, g.co, g.dout, g.ho, g.wo, g.n)
+
+
+def _conv_work(g, kind):
+    flops = 2.0 * g.n * g.co * g.ci * g.kd * g.kh * g.kw * g.dout * g.ho * g.wo
+    xin = 4.0 * g.n * g.di * g.hi * g.wi * g.ci
+    yout = 4.0 * g.n * g.dout * g.ho * g.wo * g.co
+    wts = 4.0 * g.co * g.ci * g.kd * g.kh * g.kw
+    return {"flops": flops, "bytes": xin + yout + wts}
+
+
 def _triple(v):
     if isinstance(v, (tuple, list)):
         if len(v) == 1:
@@ -116,8 +173,9 @@ def _conv_fwd(g, x, w, b):
     y = _new((g.n, g.co, g.dout, g.ho, g.wo), x)
     nb = L.mri3d_conv3d_workspace_bytes(ctypes.byref(g), PASS_FWD)
     ws = _workspace(nb, x.device)
-    check(L.mri3d_conv3d_fwd(ctypes.byref(g), _ptr(x), _ptr(w), _ptr(b), _ptr(y), _ptr(ws), ws.numel(), _stream()),
-          "conv3d_fwd")
+    with _timed(_conv_tag("fwd", g), _conv_work(g, "fwd")):
+        check(L.mri3d_conv3d_fwd(ctypes.byref(g), _ptr(x), _ptr(w), _ptr(b), _ptr(y), _ptr(ws), ws.numel(), _stream()),
+              "conv3d_fwd")
     return y
 
 
@@ -126,8 +184,9 @@ def _conv_dgrad(g, dy, w, b, like):
     dx = _new((g.n, g.ci, g.di, g.hi, g.wi), like)
     nb = L.mri3d_conv3d_workspace_bytes(ctypes.byref(g), PASS_DGRAD)
     ws = _workspace(nb, dy.device)
-    check(L.mri3d_conv3d_dgrad(ctypes.byref(g), _ptr(dy), _ptr(w), _ptr(b), _ptr(dx), _ptr(ws), ws.numel(), _stream()),
-          "conv3d_dgrad")
+    with _timed(_conv_tag("dgrad", g), _conv_work(g, "dgrad")):
+        check(L.mri3d_conv3d_dgrad(ctypes.byref(g), _ptr(dy), _ptr(w), _ptr(b), _ptr(dx), _ptr(ws), ws.numel(),
+                                   _stream()), "conv3d_dgrad")
     return dx
 
 
@@ -137,8 +196,9 @@ def _conv_wgrad(g, x, dy, w_like, want_bias):
     db = torch.empty(g.co, dtype=w_like.dtype, device=w_like.device) if want_bias else None
     nb = L.mri3d_conv3d_workspace_bytes(ctypes.byref(g), PASS_WGRAD)
     ws = _workspace(nb, x.device)
-    check(L.mri3d_conv3d_wgrad(ctypes.byref(g), _ptr(x), _ptr(dy), _ptr(dw), _ptr(db), _ptr(ws), ws.numel(), _stream()),
-          "conv3d_wgrad")
+    with _timed(_conv_tag("wgrad", g), _conv_work(g, "wgrad")):
+        check(L.mri3d_conv3d_wgrad(ctypes.byref(g), _ptr(x), _ptr(dy), _ptr(dw), _ptr(db), _ptr(ws), ws.numel(),
+                                   _stream()), "conv3d_wgrad")
     return dw, db
 
 
@@ -256,15 +316,18 @@ class _NormActFn(torch.autograd.Function):
             invstd = torch.empty(groups * c, dtype=torch.float32, device=x.device)
             ws = _workspace(L.mri3d_norm_workspace_bytes(ctypes.byref(g)), x.device)
             upd = stats_mode == "batch" and running_mean is not None
-            check(L.mri3d_norm_stats(ctypes.byref(g), _ptr(x), _ptr(mean), _ptr(invstd),
-                                     _ptr(running_mean) if upd else None, _ptr(running_var) if upd else None,
-                                     float(momentum), _ptr(ws), ws.numel(), _stream()), "norm_stats")
+            with _timed("norm_stats c%d vox%d n%d" % (c, g.vox, n), {"flops": 0.0, "bytes": 4.0 * x.numel()}):
+                check(L.mri3d_norm_stats(ctypes.byref(g), _ptr(x), _ptr(mean), _ptr(invstd),
+                                         _ptr(running_mean) if upd else None, _ptr(running_var) if upd else None,
+                                         float(momentum), _ptr(ws), ws.numel(), _stream()), "norm_stats")
         elif stats_mode == "running":
             mean = running_mean.detach().to(torch.float32).contiguous()
             invstd = torch.rsqrt(running_var.detach().to(torch.float32) + eps).contiguous()
         y = _new(x.shape, x)
-        check(L.mri3d_norm_act_fwd(ctypes.byref(g), _ptr(x), _ptr(mean), _ptr(invstd), _ptr(gamma), _ptr(beta),
-                                   _ptr(alpha) if act_code == ACT_PRELU else None, _ptr(y), _stream()), "norm_act_fwd")
+        with _timed("norm_act_fwd c%d vox%d n%d" % (c, g.vox, n), {"flops": 0.0, "bytes": 8.0 * x.numel()}):
+            check(L.mri3d_norm_act_fwd(ctypes.byref(g), _ptr(x), _ptr(mean), _ptr(invstd), _ptr(gamma), _ptr(beta),
+                                       _ptr(alpha) if act_code == ACT_PRELU else None, _ptr(y), _stream()),
+                  "norm_act_fwd")
         ctx.save_for_backward(x, mean, invstd, gamma, beta, alpha)
         ctx.geom = g
         ctx.training_stats = stats_mode in ("batch", "instance")
@@ -282,10 +345,11 @@ class _NormActFn(torch.autograd.Function):
         prelu = g.act == ACT_PRELU
         dalpha = torch.empty_like(alpha) if (prelu and ctx.needs_input_grad[3]) else None
         ws = _workspace(L.mri3d_norm_workspace_bytes(ctypes.byref(g)), x.device)
-        check(L.mri3d_norm_act_bwd(ctypes.byref(g), 1 if ctx.training_stats else 0, _ptr(x), _ptr(dy), _ptr(mean),
-                                   _ptr(invstd), _ptr(gamma), _ptr(beta), _ptr(alpha) if prelu else None, _ptr(dx),
-                                   _ptr(dgamma), _ptr(dbeta), _ptr(dalpha), _ptr(ws), ws.numel(), _stream()),
-              "norm_act_bwd")
+        with _timed("norm_act_bwd c%d vox%d n%d" % (g.c, g.vox, g.n), {"flops": 0.0, "bytes": 20.0 * x.numel()}):
+            check(L.mri3d_norm_act_bwd(ctypes.byref(g), 1 if ctx.training_stats else 0, _ptr(x), _ptr(dy), _ptr(mean),
+                                       _ptr(invstd), _ptr(gamma), _ptr(beta), _ptr(alpha) if prelu else None, _ptr(dx),
+                                       _ptr(dgamma), _ptr(dbeta), _ptr(dalpha), _ptr(ws), ws.numel(), _stream()),
+                  "norm_act_bwd")
         return dx, dgamma, dbeta, dalpha, None, None, None, None, None, None, None
 
 
@@ -365,7 +429,8 @@ class _MaxPool3dFn(torch.autograd.Function):
         g = PoolGeom(n, d, h, w, do, ho, wo, c, *kernel, *stride, *padding, c, c, F32)
         y = _new((n, c, do, ho, wo), x)
         idx = torch.empty(n * do * ho * wo * c, dtype=torch.uint8, device=x.device)
-        check(L.mri3d_maxpool3d_fwd(ctypes.byref(g), _ptr(x), _ptr(y), _ptr(idx), _stream()), "maxpool3d_fwd")
+        with _timed("maxpool_fwd c%d" % c, {"flops": 0.0, "bytes": 4.0 * x.numel() + 5.0 * y.numel()}):
+            check(L.mri3d_maxpool3d_fwd(ctypes.byref(g), _ptr(x), _ptr(y), _ptr(idx), _stream()), "maxpool3d_fwd")
         ctx.save_for_backward(idx)
         ctx.geom = g
         ctx.xshape = tuple(x.shape)
@@ -377,7 +442,9 @@ class _MaxPool3dFn(torch.autograd.Function):
         (idx,) = ctx.saved_tensors
         dy = _cl(dy)
         dx = _new(ctx.xshape, dy)
-        check(L.mri3d_maxpool3d_bwd(ctypes.byref(ctx.geom), _ptr(dy), _ptr(idx), _ptr(dx), _stream()), "maxpool3d_bwd")
+        with _timed("maxpool_bwd c%d" % ctx.geom.c, {"flops": 0.0, "bytes": 4.0 * dx.numel() + 5.0 * dy.numel()}):
+            check(L.mri3d_maxpool3d_bwd(ctypes.byref(ctx.geom), _ptr(dy), _ptr(idx), _ptr(dx), _stream()),
+                  "maxpool3d_bwd")
         return dx, None, None, None
 
 
@@ -400,7 +467,8 @@ class _Upsample3dFn(torch.autograd.Function):
         do, ho, wo = out_size
         g = UpGeom(n, d, h, w, do, ho, wo, c, c, c, mode, 1 if align_corners else 0, ratios[0], ratios[1], ratios[2], F32)
         y = _new((n, c, do, ho, wo), x)
-        check(L.mri3d_upsample3d_fwd(ctypes.byref(g), _ptr(x), _ptr(y), _stream()), "upsample3d_fwd")
+        with _timed("upsample_fwd c%d" % c, {"flops": 0.0, "bytes": 4.0 * (x.numel() + y.numel())}):
+            check(L.mri3d_upsample3d_fwd(ctypes.byref(g), _ptr(x), _ptr(y), _stream()), "upsample3d_fwd")
         ctx.geom = g
         ctx.xshape = tuple(x.shape)
         return y
@@ -412,8 +480,9 @@ class _Upsample3dFn(torch.autograd.Function):
         dy = _cl(dy)
         dx = _new(ctx.xshape, dy)
         ws = _workspace(L.mri3d_upsample3d_workspace_bytes(ctypes.byref(g)), dy.device)
-        check(L.mri3d_upsample3d_bwd(ctypes.byref(g), _ptr(dy), _ptr(dx), _ptr(ws), ws.numel(), _stream()),
-              "upsample3d_bwd")
+        with _timed("upsample_bwd c%d" % g.c, {"flops": 0.0, "bytes": 4.0 * (dx.numel() + dy.numel())}):
+            check(L.mri3d_upsample3d_bwd(ctypes.byref(g), _ptr(dy), _ptr(dx), _ptr(ws), ws.numel(), _stream()),
+                  "upsample3d_bwd")
         return dx, None, None, None, None
 
 

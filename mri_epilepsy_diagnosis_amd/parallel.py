@@ -1,0 +1,112 @@
+"""Data-parallel plumbing for one-process-per-GPU training over RCCL/xGMI (torch.distributed backend "nccl").
+
+The reference has no distributed code at all; volumes are independent, so the path shards as pure
+data parallelism: every rank runs the full model on its own volumes and the only exchange is ONE all-reduce(sum) of
+a flat gradient buffer per step (0.99 MB for the c0=8 U-Net: latency-bound, so one collective, no bucketing), with
+the 1/world_size averaging folded into the fused optimizer step (`FlatAdam`).
+
+`FlatParams` re-homes every parameter (and its .grad) as a view into one contiguous fp32 buffer, so the collective
+and the optimizer each touch a single allocation.  BatchNorm statistics stay local to each rank by default (the
+per-GPU batch is what the reference's single-GPU batch was); this is stated in DESIGN.md.
+"""
+import ctypes
+
+import torch
+import torch.distributed as dist
+
+from . import _lib
+
+
+class FlatParams:
+    """Flatten a module's trainable parameters and gradients into two contiguous buffers (views stay live)."""
+
+    def __init__(self, module):
+        seen, params = set(), []
+        for p in module.parameters():
+            if p.requires_grad and id(p) not in seen:
+                seen.add(id(p))
+                params.append(p)
+        if not params:
+            raise ValueError("module has no trainable parameters")
+        dev, dt = params[0].device, params[0].dtype
+        total = sum(p.numel() for p in params)
+        self.params = params
+        self.flat = torch.empty(total, device=dev, dtype=dt)
+        self.grad = torch.zeros(total, device=dev, dtype=dt)
+        off = 0
+        for p in params:
+            n = p.numel()
+            self.flat[off:off + n].copy_(p.data.reshape(-1))
+            p.data = self.flat[off:off + n].view(p.shape)
+            p.grad = self.grad[off:off + n].view(p.shape)
+            off += n
+
+    def zero_grad(self):
+        self.grad.zero_()
+        off = 0
+        for p in self.params:  # re-attach views if a caller dropped them (optimizer.zero_grad(set_to_none=True))
+            n = p.numel()
+            if p.grad is None or p.grad.data_ptr() != self.grad.data_ptr() + off * self.grad.element_size():
+                p.grad = self.grad[off:off + n].view(p.shape)
+            off += n
+
+    def all_reduce(self, group=None):
+        """Sum gradients over ranks in one collective.  Returns the factor the optimizer must scale by."""
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+            dist.all_reduce(self.grad, op=dist.ReduceOp.SUM, group=group)
+            return 1.0 / dist.get_world_size(group)
+        return 1.0
+
+
+class FlatAdam:
+    """Adam / AdamW over a FlatParams buffer in ONE HIP kernel (mri3d_adam_step).  Matches torch.optim.AdamW
+    (decoupled=True; segmentation/routine.py:358) or torch.optim.Adam with L2 weight_decay (decoupled=False;
+    classification/routine.py:271) single-tensor arithmetic."""
+
+    def __init__(self, flat, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2, decoupled=True):
+        self.flat = flat
+        self.param_groups = [dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, params=flat.params)]
+        self.decoupled = decoupled
+        self.m = torch.zeros_like(flat.flat)
+        self.v = torch.zeros_like(flat.flat)
+        self.step_count = 0
+
+    def zero_grad(self, set_to_none=False):
+        self.flat.zero_grad()
+
+    def step(self, grad_scale=1.0):
+        if not self.flat.flat.is_cuda:
+            raise RuntimeError("FlatAdam runs on the HIP kernel only; parameters must live on a ROCm device")
+        g = self.param_groups[0]
+        self.step_count += 1
+        L = _lib.lib()
+        p = ctypes.c_void_p
+        _lib.check(L.mri3d_adam_step(p(self.flat.flat.data_ptr()), p(self.flat.grad.data_ptr()), p(self.m.data_ptr()),
+                                     p(self.v.data_ptr()), self.flat.flat.numel(), float(g["lr"]), float(g["betas"][0]),
+                                     float(g["betas"][1]), float(g["eps"]), float(g["weight_decay"]), self.step_count,
+                                     float(grad_scale), 1 if self.decoupled else 0,
+                                     p(torch.cuda.current_stream().cuda_stream)), "adam_step")
+
+
+def init_from_env(backend=None):
+    """Initialise torch.distributed from RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* (torchrun).  Returns
+    (rank, local_rank, world_size).  No-op (0, 0, 1) when WORLD_SIZE is unset or 1."""
+    import os
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1 and not dist.is_initialized():
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        if backend == "nccl":
+            torch.cuda.set_device(local)
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return rank, local, world
+
+
+def shard_range(n_items, rank, world):
+    """Contiguous [lo, hi) slice of n_items for `rank` (independent volumes: no data-path collective)."""
+    base, rem = divmod(n_items, world)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)

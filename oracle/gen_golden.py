@@ -140,7 +140,9 @@ def main():
     assert_same_state(ref, orc)
     x = seeded_randn(31, (2, 1, 64, 64, 64))
     np.savez(os.path.join(OUT, "ae_93_6_4_64.npz"), **record(ref, orc, x, lambda o: F.mse_loss(o, x), train=True))
-    # odd size: exercises the F.interpolate(size=) fix-up of UpBlock (AE_model.py:116-119)
+    # odd size: exercises the F.interpolate(size=) fix-up of UpBlock (AE_model.py:116-119); fresh modules
+    torch.manual_seed(0); ref = R_AE.AE(**AE_KWARGS_93_6_4)
+    torch.manual_seed(0); orc = O_AE.AE(**AE_KWARGS_93_6_4)
     x = seeded_randn(32, (2, 1, 72, 80, 68))
     np.savez(os.path.join(OUT, "ae_93_6_4_odd.npz"), **record(ref, orc, x, lambda o: F.mse_loss(o, x), train=True))
     print("ae ok")

@@ -1,0 +1,328 @@
+"""GPU parity suite, operator level: every HIP operator (forward AND backward, called through the C ABI via the
+autograd seam) against the same op in plain PyTorch fp32 on the CPU — the reference's L2 semantics.
+Tolerance: max-norm relative error <= 1e-3 (north_star); index/byte outputs bit-exact."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from mri_epilepsy_diagnosis_amd import ops
+from util import assert_close, seeded_rand, seeded_randn, to_ncdhw
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def _dev(t, grad=True):
+    d = t.to(DEV).contiguous(memory_format=torch.channels_last_3d) if t.dim() == 5 else t.to(DEV)
+    return d.requires_grad_(grad) if grad else d
+
+
+# ---------------------------------------------------------------------------------------------- conv
+CONV_CASES = [
+    # name, N, Cin, Cout, (D,H,W), k, s, p, d, bias
+    ("unet_1_8", 2, 1, 8, (12, 20, 16), 3, 1, 1, 1, True),
+    ("unet_8_16", 2, 8, 16, (12, 20, 16), 3, 1, 1, 1, True),
+    ("unet_16_16", 1, 16, 16, (16, 12, 20), 3, 1, 1, 1, True),
+    ("unet_16_32", 1, 16, 32, (8, 12, 16), 3, 1, 1, 1, True),
+    ("unet_32_32", 1, 32, 32, (8, 12, 8), 3, 1, 1, 1, True),
+    ("unet_32_64", 1, 32, 64, (8, 6, 8), 3, 1, 1, 1, True),
+    ("unet_96_32", 1, 96, 32, (8, 8, 12), 3, 1, 1, 1, True),
+    ("unet_48_16", 1, 48, 16, (12, 16, 16), 3, 1, 1, 1, True),
+    ("unet_cls_16_2", 2, 16, 2, (12, 20, 16), 1, 1, 0, 1, True),
+    ("ragged_3x3x3", 1, 16, 16, (5, 7, 9), 3, 1, 1, 1, False),
+    ("tiny_1voxel", 1, 8, 16, (1, 1, 1), 3, 1, 1, 1, True),
+    ("sepx_k6s2p2", 2, 1, 8, (32, 12, 10), (6, 1, 1), (2, 1, 1), (2, 0, 0), 1, True),
+    ("sepy_k6s2p2", 2, 8, 8, (8, 24, 10), (1, 6, 1), (1, 2, 1), (0, 2, 0), 1, True),
+    ("sepz_k6s2p2", 2, 8, 16, (8, 6, 28), (1, 1, 6), (1, 1, 2), (0, 0, 2), 1, True),
+    ("sepx_k3p0", 3, 32, 64, (3, 3, 3), (3, 1, 1), 1, 0, 1, True),
+    ("sepz_k3p1", 1, 16, 8, (6, 5, 9), (1, 1, 3), 1, (0, 0, 1), 1, True),
+    ("stride2_m3d", 1, 8, 16, (12, 10, 14), 3, 2, 1, 1, False),
+    ("stride2_odd", 1, 16, 32, (9, 7, 11), 3, 2, 1, 1, False),
+    ("dilated_s2", 1, 1, 4, (25, 23, 27), 3, 2, 0, 3, True),
+    ("dilated_p3", 1, 4, 4, (11, 12, 13), 3, 1, 3, 3, True),
+    ("reduce_k4s4", 1, 1, 1, (16, 12, 8), 4, 4, 0, 1, True),
+    ("vox_1_1", 2, 1, 1, (9, 10, 11), 3, 1, 1, 1, True),
+    ("odd_channels", 1, 3, 5, (6, 7, 8), 3, 1, 1, 1, True),
+    ("wide_128", 1, 128, 128, (4, 4, 4), 3, 1, 1, 1, False),
+]
+
+
+@pytest.mark.parametrize("case", CONV_CASES, ids=[c[0] for c in CONV_CASES])
+def test_conv3d_fwd_dgrad_wgrad(case):
+    _, n, ci, co, sp, k, s, p, d, bias = case
+    x = seeded_randn(1, (n, ci, *sp))
+    conv = torch.nn.Conv3d(ci, co, k, s, p, d, bias=bias)
+    torch.manual_seed(2)
+    with torch.no_grad():
+        conv.weight.copy_(torch.randn_like(conv.weight) * 0.2)
+        if bias:
+            conv.bias.copy_(torch.randn_like(conv.bias))
+    xr = x.clone().requires_grad_(True)
+    yr = conv(xr)
+    gy = seeded_randn(3, tuple(yr.shape))
+    yr.backward(gy)
+
+    xd = _dev(x)
+    w = conv.weight.detach().to(DEV).requires_grad_(True)
+    b = conv.bias.detach().to(DEV).requires_grad_(True) if bias else None
+    yd = ops.conv3d(xd, w, b, s, p, d)
+    assert tuple(yd.shape) == tuple(yr.shape)
+    yd.backward(_dev(gy, False))
+    assert_close(to_ncdhw(yd), yr, what="y")
+    assert_close(to_ncdhw(xd.grad), xr.grad, what="dx")
+    assert_close(w.grad.cpu(), conv.weight.grad, what="dw")
+    if bias:
+        assert_close(b.grad.cpu(), conv.bias.grad, what="db")
+
+
+def test_conv3d_is_deterministic_and_linear():
+    x = _dev(seeded_randn(5, (1, 16, 12, 12, 12)), False)
+    w = seeded_randn(6, (16, 16, 3, 3, 3)).to(DEV)
+    y1 = ops.conv3d(x, w, None, 1, 1, 1)
+    y2 = ops.conv3d(x, w, None, 1, 1, 1)
+    assert torch.equal(y1, y2)
+    y3 = ops.conv3d(x * 2.0, w, None, 1, 1, 1)
+    assert torch.equal(y3, y1 * 2.0)  # exact: scaling by 2 commutes with fp32 rounding
+
+
+CT_CASES = [("k2s2", 1, 6, 6, (5, 6, 7), 2, 2, 0, 0), ("k4s4_1_1", 2, 1, 1, (3, 4, 5), 4, 4, 0, 0),
+            ("k4s2p1", 1, 8, 4, (5, 5, 6), 4, 2, 1, 0), ("k3s2p1op1", 1, 4, 8, (4, 5, 3), 3, 2, 1, 1)]
+
+
+@pytest.mark.parametrize("case", CT_CASES, ids=[c[0] for c in CT_CASES])
+def test_conv_transpose3d(case):
+    _, n, ci, co, sp, k, s, p, op = case
+    m = torch.nn.ConvTranspose3d(ci, co, k, s, p, op)
+    x = seeded_randn(1, (n, ci, *sp))
+    xr = x.clone().requires_grad_(True)
+    yr = m(xr)
+    gy = seeded_randn(2, tuple(yr.shape))
+    yr.backward(gy)
+    xd = _dev(x)
+    w = m.weight.detach().to(DEV).requires_grad_(True)
+    b = m.bias.detach().to(DEV).requires_grad_(True)
+    yd = ops.conv_transpose3d(xd, w, b, s, p, op, 1)
+    yd.backward(_dev(gy, False))
+    assert_close(to_ncdhw(yd), yr, what="y")
+    assert_close(to_ncdhw(xd.grad), xr.grad, what="dx")
+    assert_close(w.grad.cpu(), m.weight.grad, what="dw")
+    assert_close(b.grad.cpu(), m.bias.grad, what="db")
+
+
+# ---------------------------------------------------------------------------------------------- norm + activation
+def _ref_act(kind, alpha, slope):
+    if kind is None:
+        return lambda t: t
+    if kind == "relu":
+        return F.relu
+    if kind == "leaky_relu":
+        return lambda t: F.leaky_relu(t, slope)
+    return lambda t: F.prelu(t, alpha)
+
+
+NORM_CASES = [(mode, act, c, an) for mode in ("batch", "instance", "running", "none")
+              for act, c, an in ((None, 16, 1), ("relu", 8, 1), ("leaky_relu", 32, 1), ("prelu", 16, 1), ("prelu", 12, 12),
+                                 ("prelu", 3, 1))]
+
+
+@pytest.mark.parametrize("mode,act,c,alpha_n", NORM_CASES)
+def test_norm_act_fwd_bwd(mode, act, c, alpha_n):
+    if mode == "none" and act is None:
+        pytest.skip("identity")
+    n, sp = 3, (6, 10, 7)
+    x = seeded_randn(1, (n, c, *sp)) * 1.7 + 0.9
+    gamma = seeded_randn(2, (c,)) * 0.5 + 1.0
+    beta = seeded_randn(3, (c,)) * 0.3
+    alpha = (seeded_rand(4, (alpha_n,)) * 0.5 - 0.1)
+    rm = seeded_randn(5, (c,)) * 0.1 + 0.8
+    rv = seeded_rand(6, (c,)) + 2.0
+    affine = mode != "none"
+
+    xr = x.clone().requires_grad_(True)
+    gr, br, ar = gamma.clone().requires_grad_(affine), beta.clone().requires_grad_(affine), alpha.clone().requires_grad_(True)
+    rm_r, rv_r = rm.clone(), rv.clone()
+    if mode == "batch":
+        t = F.batch_norm(xr, rm_r, rv_r, gr, br, True, 0.1, 1e-5)
+    elif mode == "running":
+        t = F.batch_norm(xr, rm_r, rv_r, gr, br, False, 0.1, 1e-5)
+    elif mode == "instance":
+        t = F.instance_norm(xr, None, None, gr, br, True, 0.1, 1e-5)
+    else:
+        t = xr
+    yr = _ref_act(act, ar, 0.01)(t)
+    gy = seeded_randn(7, tuple(yr.shape))
+    yr.backward(gy)
+
+    xd = _dev(x)
+    gd = gamma.to(DEV).requires_grad_(True) if affine else None
+    bd = beta.to(DEV).requires_grad_(True) if affine else None
+    ad = alpha.to(DEV).requires_grad_(True) if act == "prelu" else None
+    rm_d, rv_d = rm.to(DEV), rv.to(DEV)
+    yd = ops.norm_act(xd, gd, bd, ad, rm_d if mode in ("batch", "running") else None,
+                      rv_d if mode in ("batch", "running") else None, mode, 0.1, 1e-5, act, 0.01)
+    yd.backward(_dev(gy, False))
+    assert_close(to_ncdhw(yd), yr, what="y")
+    assert_close(to_ncdhw(xd.grad), xr.grad, what="dx")
+    if affine:
+        assert_close(gd.grad.cpu(), gr.grad, what="dgamma")
+        assert_close(bd.grad.cpu(), br.grad, what="dbeta")
+    if act == "prelu":
+        assert_close(ad.grad.cpu(), ar.grad, what="dalpha")
+    if mode == "batch":
+        assert_close(rm_d.cpu(), rm_r, rel=1e-5, what="running_mean")
+        assert_close(rv_d.cpu(), rv_r, rel=1e-5, what="running_var")
+
+
+def test_batch_stats_large_offset_is_stable():
+    """mean >> std: the shifted-sum statistics must not lose the variance (E[x^2]-E[x]^2 cancellation)."""
+    x = seeded_randn(1, (2, 8, 16, 16, 16)) * 0.05 + 300.0
+    y = ops.norm_act(_dev(x, False), None, None, None, None, None, "batch", 0.1, 1e-5, None, 0.0)
+    ref = F.batch_norm(x, None, None, None, None, True, 0.1, 1e-5)
+    assert_close(to_ncdhw(y), ref, rel=5e-3, what="y")
+
+
+def test_dropout3d_masks_whole_channels():
+    x = _dev(seeded_randn(1, (4, 16, 5, 6, 7)))
+    torch.manual_seed(0)
+    y = ops.dropout3d(x, 0.6, True)
+    y.sum().backward()
+    yc, xc = to_ncdhw(y), to_ncdhw(x)
+    per = (yc != 0).flatten(2).float().mean(-1)
+    assert set(per.flatten().tolist()) <= {0.0, 1.0} and 0 < per.mean() < 1
+    keep = per.bool()
+    assert_close(yc[keep], xc[keep] / 0.4, rel=1e-6)
+    assert_close(to_ncdhw(x.grad)[keep], torch.full_like(xc[keep], 2.5), rel=1e-6)
+    assert ops.dropout3d(x, 0.6, False) is x
+
+
+# ---------------------------------------------------------------------------------------------- pooling / upsampling
+@pytest.mark.parametrize("c,sp,k,s", [(16, (8, 12, 10), 2, 2), (8, (9, 7, 11), 2, 2), (3, (6, 6, 6), 2, 2),
+                                      (4, (13, 12, 14), 4, 2), (1, (8, 8, 8), 2, 2), (64, (4, 6, 4), 2, 2)])
+def test_max_pool3d(c, sp, k, s):
+    x = seeded_randn(1, (2, c, *sp))
+    xr = x.clone().requires_grad_(True)
+    yr = F.max_pool3d(xr, k, s)
+    gy = seeded_randn(2, tuple(yr.shape))
+    yr.backward(gy)
+    xd = _dev(x)
+    yd = ops.max_pool3d(xd, k, s)
+    yd.backward(_dev(gy, False))
+    assert torch.equal(to_ncdhw(yd), yr)            # selection: bit-exact
+    assert_close(to_ncdhw(xd.grad), xr.grad, rel=1e-6, what="dx")
+
+
+def test_max_pool3d_ties_pick_first_like_torch():
+    x = torch.zeros(1, 4, 4, 4, 4)
+    xr = x.clone().requires_grad_(True)
+    F.max_pool3d(xr, 2).sum().backward()
+    xd = _dev(x)
+    ops.max_pool3d(xd, 2).sum().backward()
+    assert torch.equal(to_ncdhw(xd.grad), xr.grad)
+
+
+UP_CASES = [("nearest", None, 2, None, 16, (5, 6, 7)), ("nearest", None, 4, None, 8, (3, 4, 2)),
+            ("nearest", (9, 11, 13), None, None, 4, (4, 5, 6)), ("nearest", (7, 7, 7), None, None, 1, (7, 3, 9)),
+            ("trilinear", None, 2, False, 32, (5, 6, 4)), ("trilinear", None, 2, True, 8, (5, 6, 4)),
+            ("trilinear", (7, 9, 11), None, False, 4, (4, 5, 6)), ("trilinear", None, 2, False, 3, (1, 4, 5))]
+
+
+@pytest.mark.parametrize("mode,size,scale,ac,c,sp", UP_CASES)
+def test_upsample3d(mode, size, scale, ac, c, sp):
+    x = seeded_randn(1, (2, c, *sp))
+    xr = x.clone().requires_grad_(True)
+    yr = F.interpolate(xr, size=size, scale_factor=scale, mode=mode, align_corners=ac)
+    gy = seeded_randn(2, tuple(yr.shape))
+    yr.backward(gy)
+    xd = _dev(x)
+    yd = ops.upsample3d(xd, size=size, scale_factor=scale, mode=mode, align_corners=ac)
+    assert tuple(yd.shape) == tuple(yr.shape)
+    yd.backward(_dev(gy, False))
+    assert_close(to_ncdhw(yd), yr, rel=1e-5, what="y")
+    assert_close(to_ncdhw(xd.grad), xr.grad, rel=1e-5, what="dx")
+
+
+# ---------------------------------------------------------------------------------------------- loss / mask / plumbing
+@pytest.mark.parametrize("n,c,ct,sp", [(1, 2, 1, (8, 8, 8)), (2, 2, 1, (9, 7, 5)), (2, 3, 3, (6, 6, 6)), (1, 2, 2, (4, 4, 4))])
+def test_softmax_dice_loss(n, c, ct, sp):
+    from oracle import losses
+    lg = seeded_randn(1, (n, c, *sp)) * 2
+    tg = (seeded_rand(2, (n, ct, *sp)) < 0.3).float()
+    lr = lg.clone().requires_grad_(True)
+    loss_r = losses.softmax_dice_loss(lr, tg)
+    (loss_r * 1.7).backward()
+    ld = _dev(lg)
+    loss_d = ops.softmax_dice_loss(ld, _dev(tg, False))
+    (loss_d * 1.7).backward()
+    assert_close(loss_d.cpu(), loss_r.detach(), rel=1e-5, what="loss")
+    assert_close(to_ncdhw(ld.grad), lr.grad, what="dlogits")
+
+
+def test_softmax_dice_known_answer(golden_dir):
+    g = np.load(golden_dir + "/dice_known.npz")
+    loss = ops.softmax_dice_loss(_dev(torch.from_numpy(g["logits"]), False), _dev(torch.from_numpy(g["target"]), False))
+    np.testing.assert_allclose(loss.item(), float(g["loss"]), rtol=1e-5)
+
+
+def test_softmax_dice_empty_target_and_all_foreground():
+    lg = _dev(seeded_randn(1, (1, 2, 6, 6, 6)), False)
+    for fill in (0.0, 1.0):
+        tg = torch.full((1, 1, 6, 6, 6), fill)
+        from oracle import losses
+        ref = losses.softmax_dice_loss(lg.cpu().contiguous(memory_format=torch.contiguous_format), tg)
+        assert_close(ops.softmax_dice_loss(lg, _dev(tg, False)).cpu(), ref, rel=1e-5)
+
+
+def test_argmax_mask_bit_exact():
+    lg = seeded_randn(1, (2, 2, 9, 10, 11))
+    lg[0, :, 0, 0, 0] = 0.5  # tie -> class 0
+    m = ops.argmax_mask(_dev(lg, False))
+    assert m.dtype == torch.uint8 and torch.equal(m.cpu(), lg.argmax(dim=1).to(torch.uint8))
+    lg3 = seeded_randn(2, (1, 5, 4, 4, 4))
+    assert torch.equal(ops.argmax_mask(_dev(lg3, False)).cpu(), lg3.argmax(dim=1).to(torch.uint8))
+
+
+def test_cat_and_add():
+    a, b, c = seeded_randn(1, (2, 16, 4, 5, 6)), seeded_randn(2, (2, 32, 4, 5, 6)), seeded_randn(3, (2, 3, 4, 5, 6))
+    ad, bd, cd = _dev(a), _dev(b), _dev(c)
+    y = ops.cat_channels([ad, bd, cd])
+    gy = seeded_randn(4, tuple(y.shape))
+    y.backward(_dev(gy, False))
+    assert torch.equal(to_ncdhw(y), torch.cat([a, b, c], 1))
+    assert torch.equal(to_ncdhw(ad.grad), gy[:, :16]) and torch.equal(to_ncdhw(bd.grad), gy[:, 16:48])
+    assert torch.equal(to_ncdhw(cd.grad), gy[:, 48:])
+    a2, b2 = _dev(a), _dev(seeded_randn(5, tuple(a.shape)))
+    s = ops.add(a2, b2)
+    s.backward(_dev(gy[:, :16].contiguous(), False))
+    assert torch.equal(to_ncdhw(s), a + to_ncdhw(b2)) and torch.equal(to_ncdhw(a2.grad), gy[:, :16])
+
+
+def test_flat_adam_matches_torch_adamw_and_adam():
+    from mri_epilepsy_diagnosis_amd import parallel
+    for decoupled, ref_cls in ((True, torch.optim.AdamW), (False, torch.optim.Adam)):
+        torch.manual_seed(0)
+        lin_r = torch.nn.Sequential(torch.nn.Linear(7, 5), torch.nn.Linear(5, 3))
+        lin_d = torch.nn.Sequential(torch.nn.Linear(7, 5), torch.nn.Linear(5, 3))
+        lin_d.load_state_dict(lin_r.state_dict())
+        lin_d.to(DEV)
+        fp = parallel.FlatParams(lin_d)
+        opt_d = parallel.FlatAdam(fp, lr=1e-2, weight_decay=0.05, decoupled=decoupled)
+        opt_r = ref_cls(lin_r.parameters(), lr=1e-2, weight_decay=0.05)
+        for it in range(4):
+            x = seeded_randn(10 + it, (6, 7))
+            opt_r.zero_grad(); lin_r(x).pow(2).mean().backward(); opt_r.step()
+            opt_d.zero_grad(); lin_d(x.to(DEV)).pow(2).mean().backward(); opt_d.step(fp.all_reduce())
+        for pr, pd in zip(lin_r.parameters(), lin_d.parameters()):
+            assert_close(pd.detach().cpu(), pr.detach(), rel=1e-5)
+
+
+def test_unsupported_and_invalid_arguments_raise():
+    x = _dev(seeded_randn(1, (1, 4, 4, 4, 4)), False)
+    with pytest.raises(RuntimeError, match="input channels"):
+        ops.conv3d(x, torch.randn(2, 3, 3, 3, 3, device=DEV))
+    with pytest.raises(RuntimeError, match="greater than actual input size"):
+        ops.conv3d(x, torch.randn(2, 4, 5, 5, 5, device=DEV))     # reference behaviour for the 160x192x160 head
+    with pytest.raises(RuntimeError):
+        ops.conv3d(x.half(), torch.randn(2, 4, 3, 3, 3, device=DEV).half())
+    with pytest.raises(RuntimeError):
+        ops.softmax_dice_loss(x, _dev(torch.zeros(1, 2, 4, 4, 4), False))

@@ -1,0 +1,123 @@
+"""CPU suite: the oracle restatements reproduce the golden vectors recorded from the REFERENCE modules
+(oracle/gen_golden.py, run in the authoring container with /root/reference importable), and strict-load the
+reference's shipped checkpoints.  This is what pins the oracle before any HIP kernel is compared with it."""
+import hashlib
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import ae_model as O_AE, cnn_model as O_CNN, losses, modified_3dunet as O_M, unet_recon
+from util import (AE_KWARGS_93_6_4, CLF_KWARGS, DISC_KWARGS, grad_norms, load_ckpt, load_golden, param_checksum, sample,
+                  seeded_rand, seeded_randn)
+
+
+def _check(model, x, loss_fn, train, gold, exact=True):
+    model.train(train)
+    model.zero_grad(set_to_none=True)
+    out = model(x)
+    out = out[0] if isinstance(out, tuple) else out
+    loss = loss_fn(out)
+    loss.backward()
+    np.testing.assert_array_equal(param_checksum(model), gold["param_checksum"])
+    smp, stride = sample(out)
+    assert stride == int(gold["out_stride"]) and list(out.shape) == list(gold["out_shape"])
+    if exact:  # same torch build, same CPU kernels: bit-for-bit
+        np.testing.assert_array_equal(smp, gold["out_sample"])
+    np.testing.assert_allclose(smp, gold["out_sample"], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(loss.item(), float(gold["loss"]), rtol=1e-6)
+    np.testing.assert_allclose(grad_norms(model), gold["grad_norms"], rtol=1e-5, atol=1e-9)
+
+
+def test_modified3dunet_matches_reference_vectors():
+    torch.manual_seed(0)
+    m = O_M.Modified3DUNet(1, 2, 8)
+    x = seeded_randn(11, (1, 1, 32, 32, 32))
+    tgt = (seeded_rand(12, (1, 1, 32, 32, 32)) < 0.2).float()
+    _check(m, x, lambda o: losses.softmax_dice_loss(o, tgt), False, load_golden("modified3dunet_b8_32.npz"), exact=False)
+
+
+@pytest.mark.parametrize("name,cls,kw,shape", [
+    ("cnn_32", "CNN", dict(input_shape=(32, 32, 32), n_filters=16, n_blocks=3), (4, 1, 32, 32, 32)),
+    ("voxresnet_32", "VoxResNet", dict(input_shape=(32, 32, 32), n_filters=8, n_blocks=3), (3, 1, 32, 32, 32)),
+])
+def test_cnn_family_matches_reference_vectors(name, cls, kw, shape):
+    torch.manual_seed(0)
+    m = getattr(O_CNN, cls)(**kw)
+    x = seeded_randn(21, shape)
+    y = torch.arange(shape[0]) % 2
+    _check(m, x, lambda o: F.cross_entropy(o[:, :2], y), True, load_golden(name + ".npz"), exact=False)
+
+
+@pytest.mark.parametrize("name,seed,shape", [("ae_93_6_4_64", 31, (2, 1, 64, 64, 64)), ("ae_93_6_4_odd", 32, (2, 1, 72, 80, 68))])
+def test_ae_matches_reference_vectors(name, seed, shape):
+    torch.manual_seed(0)
+    m = O_AE.AE(**AE_KWARGS_93_6_4)
+    x = seeded_randn(seed, shape)
+    _check(m, x, lambda o: F.mse_loss(o, x), True, load_golden(name + ".npz"), exact=False)
+
+
+def test_shipped_classification_checkpoints_strict_load_and_head_outputs():
+    enc = O_AE.AE(**AE_KWARGS_93_6_4).enc
+    clf = O_AE.Classificator(**CLF_KWARGS)
+    disc = O_AE.Discriminator(**DISC_KWARGS)
+    enc.load_state_dict(load_ckpt("encoder_93_6_4.pth"), strict=True)
+    clf.load_state_dict(load_ckpt("clf_93_6_4.pth"), strict=True)
+    disc.load_state_dict(load_ckpt("disc_93_6_4.pth"), strict=True)
+    gold = load_golden("enc_clf_disc_ckpt_192.npz")
+    lat = torch.from_numpy(gold["latent"])
+    clf.eval(); disc.eval()
+    with torch.no_grad():
+        np.testing.assert_allclose(clf(lat).numpy(), gold["clf"], rtol=1e-5, atol=1e-6)
+        np.testing.assert_allclose(disc(lat).numpy(), gold["disc"], rtol=1e-5, atol=1e-6)
+    assert gold["sizes"].tolist() == [[192] * 3, [48] * 3, [12] * 3]  # block INPUT sizes (AE_model.py:47-48)
+
+
+def test_dice_known_answer():
+    g = load_golden("dice_known.npz")
+    lg, tg = torch.from_numpy(g["logits"]), torch.from_numpy(g["target"])
+    per = 1 - losses.dice_score(F.softmax(lg, dim=1), tg)
+    np.testing.assert_allclose(per.numpy(), g["per_channel"], rtol=1e-6)
+    # SURVEY.md §8c known answers recorded from the reference's own get_dice_loss
+    np.testing.assert_allclose(per.numpy().ravel(), [0.6139, 0.6109], atol=5e-5)
+    np.testing.assert_allclose(per.mean().item(), 0.612425, atol=5e-6)
+
+
+def test_adv_loss_known_answer():
+    g = load_golden("adv_loss.npz")
+    v = losses.adv_loss(torch.from_numpy(g["domain"]), torch.from_numpy(g["logits"]), 18).item()
+    np.testing.assert_allclose(v, float(g["adv"]), rtol=1e-6)
+
+
+def test_unet_recon_strict_loads_reference_checkpoint_and_matches_recorded_run():
+    m = unet_recon.UNetRecon(out_channels_first_layer=8)
+    sd = load_ckpt("whole_im_train_seg_parc_epoch_7.pth")
+    assert len(sd) == 154
+    m.load_state_dict(sd, strict=True)
+    for k in sd:  # alias keys: conv_layer == block.0 etc.
+        if ".conv_layer." in k:
+            assert torch.equal(sd[k], sd[k.replace(".conv_layer.", ".block.0.")])
+    gold = load_golden("unet_c8_ckpt_32.npz")
+    x = seeded_randn(61, (1, 1, 32, 32, 32))
+    m.eval()
+    with torch.no_grad():
+        lo = m(x)
+    np.testing.assert_allclose(sample(lo)[0], gold["eval_sample"], rtol=1e-5, atol=1e-6)
+    mask = lo.argmax(dim=1).to(torch.uint8).numpy()
+    assert hashlib.sha256(mask.tobytes()).hexdigest() == str(gold["mask_sha256"])
+
+
+def test_unet_recon_loss_trajectory():
+    gold = load_golden("unet_c8_traj_32.npz")
+    torch.manual_seed(0)
+    m = unet_recon.UNetRecon(out_channels_first_layer=8)
+    opt = torch.optim.AdamW(m.parameters())
+    traj = []
+    for it in range(3):
+        x = seeded_randn(70 + it, (1, 1, 32, 32, 32))
+        tgt = (seeded_rand(80 + it, (1, 1, 32, 32, 32)) < 0.1).float()
+        opt.zero_grad()
+        loss = losses.softmax_dice_loss(m(x), tgt)
+        loss.backward(); opt.step(); traj.append(loss.item())
+    np.testing.assert_allclose(traj, gold["losses"], rtol=1e-5)
