@@ -87,6 +87,9 @@ def lib():
     """Load (once) and return the ctypes handle.  Raises if the .so was not built: no fallback exists."""
     global _lib
     if _lib is None:
+        # torch bundles its own libamdhip64.so.7; importing it first makes this library bind to the SAME HIP runtime
+        # instance (one soname, one copy per process) so that device pointers and streams are interchangeable.
+        import torch  # noqa: F401
         if not os.path.exists(LIB_PATH):
             raise Mri3dError(
                 "libmri3d_hip.so not found at %s — run `python -m mri_epilepsy_diagnosis_amd.build` "

@@ -317,14 +317,14 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ part, const float*
         int co = i / (taps * Ci);
         const float* p = part + ((size_t)tap * CiP + ci) * CoP + co;
         const size_t stride = (size_t)taps * CiP * CoP;
-        float s = 0.f;
-        for (int b = 0; b < nb; ++b) s += p[b * stride];
-        dw[i] = s;
+        double s = 0.0;
+        for (int b = 0; b < nb; ++b) s += (double)p[b * stride];
+        dw[i] = (float)s;
     }
     if (dbias != nullptr && i < Co) {
-        float s = 0.f;
-        for (int b = 0; b < nb; ++b) s += bias_part[(size_t)b * Co + i];
-        dbias[i] = s;
+        double s = 0.0;
+        for (int b = 0; b < nb; ++b) s += (double)bias_part[(size_t)b * Co + i];
+        dbias[i] = (float)s;
     }
 }
 

@@ -1,0 +1,39 @@
+"""GPU suite: precision audit against an fp64 ground truth.  Gradients that travel through ten BatchNorm layers
+amplify fp32 rounding; the bar here is that the HIP path is no further from the fp64 truth than a small multiple of
+what PyTorch's own fp32 CPU path is (which is the reference's arithmetic)."""
+import copy
+
+import pytest
+import torch
+
+from mri_epilepsy_diagnosis_amd import ops
+from mri_epilepsy_diagnosis_amd.unet import UNet
+from oracle import losses, unet_recon
+from util import seeded_rand, seeded_randn
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("c0", [8, 16])
+def test_unet_gradients_vs_fp64_truth(c0):
+    torch.manual_seed(0)
+    o32 = unet_recon.UNetRecon(out_channels_first_layer=c0)
+    o64 = copy.deepcopy(o32).double()
+    prod = UNet(in_channels=1, out_classes=2, dimensions=3, num_encoding_blocks=3, out_channels_first_layer=c0,
+                normalization="batch", upsampling_type="linear", padding=True, activation="PReLU")
+    prod.load_state_dict(o32.state_dict())
+    prod.cuda()
+    x = seeded_randn(5, (1, 1, 32, 32, 32))
+    t = (seeded_rand(6, (1, 1, 32, 32, 32)) < 0.1).float()
+    losses.softmax_dice_loss(o32(x), t).backward()
+    losses.softmax_dice_loss(o64(x.double()), t.double()).backward()
+    ops.softmax_dice_loss(prod(x.cuda()), t.cuda()).backward()
+    gmax = max(p.grad.abs().max().item() for p in o64.parameters())
+    worst_cpu = worst_hip = 0.0
+    for (k, p64), p32, pp in zip(o64.named_parameters(), o32.parameters(), prod.parameters()):
+        den = p64.grad.abs().max().item() + 1e-4 * gmax
+        e_cpu = (p32.grad.double() - p64.grad).abs().max().item() / den
+        e_hip = (pp.grad.cpu().double() - p64.grad).abs().max().item() / den
+        worst_cpu, worst_hip = max(worst_cpu, e_cpu), max(worst_hip, e_hip)
+        assert e_hip <= max(1e-3, 4.0 * e_cpu), "%s: HIP err %.2e vs fp64, CPU-fp32 err %.2e" % (k, e_hip, e_cpu)
+    print("worst grad error vs fp64: torch-CPU-fp32 %.2e, HIP %.2e" % (worst_cpu, worst_hip))
