@@ -42,11 +42,15 @@ def build_model(device):
                 normalization="batch", upsampling_type="linear", padding=True, activation="PReLU").to(device)
 
 
-def cpu_baseline(max_seconds=30.0):
+def cpu_baseline(max_seconds=25.0):
     """Oracle (CPU restatement of the reference model) fwd+bwd+AdamW on batch-1 volumes of the bench size."""
     from oracle import losses, unet_recon
     torch.manual_seed(0)
-    threads = os.cpu_count() or 1
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
+    threads = max(1, min(avail, 16))  # the GPU box's CPU share for one GPU is 16 cores; more threads only oversubscribe
     torch.set_num_threads(threads)
     m = unet_recon.UNetRecon(out_channels_first_layer=C0)
     opt = torch.optim.AdamW(m.parameters())
@@ -55,7 +59,7 @@ def cpu_baseline(max_seconds=30.0):
     t = (torch.rand(1, 1, *SHAPE, generator=g) < 0.1).float()
     times = []
     t_start = time.perf_counter()
-    for it in range(4):
+    for it in range(3):
         t0 = time.perf_counter()
         opt.zero_grad()
         loss = losses.softmax_dice_loss(m(x), t)
