@@ -1,9 +1,277 @@
-// conv_mfma.hip — placeholder until the implicit-GEMM path lands (next commit).
+// conv_mfma.hip — implicit-GEMM Conv3d 3x3x3 / stride 1 / pad 1 / dilation 1 on the fp32-input MFMA
+// (v_mfma_f32_16x16x4_f32: exact fp32 fmaf chains at 157 TFLOP/s peak, the fp32 roof of gfx950), for the hot layers
+// of the U-Net: forward, data-gradient (the same kernel on flipped/transposed weights) and weight-gradient.
+//
+//   forward   Y[v, co] = sum_{tap, ci} X[v + tap - 1, ci] * W[co, ci, tap]          GEMM  M = voxels, N = co, K = 27*ci
+//   dgrad     dX[v, ci] = sum_{tap, co} dY[v + 1 - tap, co] * W[co, ci, tap]        same kernel, K = 27*co, N = ci
+//   wgrad     dW[co, ci, tap] = sum_v X[v + tap - 1, ci] * dY[v, co]                GEMM  M = (tap, ci), N = co, K = voxels
+//
+// Data layout in HBM: NDHWC activations (voxel pitch ld), so the K = ci fibre of a voxel is contiguous.
+// LDS: one workgroup stages the (4+2) x (8+2) x (16+2) input halo tile of a 16- (or 8-) channel chunk, [voxel][ci].
+// MFMA mapping (forward): an M-tile is 16 consecutive voxels along W; lane l supplies A[i = l&15][k-group = l>>4].
+//   The K order inside a 16-channel chunk is permuted so that k-group g owns channels 4g..4g+3: one ds_read_b128 per
+//   lane feeds four consecutive MFMA k-steps (step s takes element s).  The packed weight image applies the same
+//   permutation, and is laid out so that each wave reads its B fragments as one contiguous 1 KiB global load.
+//   With 8-channel chunks two taps share a k-step (k-groups 0,1 = tap 2t, k-groups 2,3 = tap 2t+1).
+// A wave owns one d-plane of the tile = 8 M-tiles x NT N-tiles of 16 output channels (8*NT accumulators of 4 VGPRs),
+// so every B fragment is reused 8x and every A fragment NT x.
+//
+// Roofline: compute-bound for Cin*Cout >= 8*16 (AI 72..270 FLOP/B vs ridge ~20): the bound is the fp32
+// MFMA peak; algorithmic FLOPs = 2 * N*D*H*W * Cin * Cout * 27 per pass.
 #include "common.h"
+
 namespace mri3d {
-bool conv_mfma_supported(const Mri3dConvGeom&, int) { return false; }
-size_t conv_mfma_workspace_bytes(const Mri3dConvGeom&, int) { return 0; }
-int conv_mfma_fwd(const Mri3dConvGeom&, const float*, const float*, const float*, float*, void*, size_t, hipStream_t) { return MRI3D_ENOTSUP; }
-int conv_mfma_dgrad(const Mri3dConvGeom&, const float*, const float*, const float*, float*, void*, size_t, hipStream_t) { return MRI3D_ENOTSUP; }
-int conv_mfma_wgrad(const Mri3dConvGeom&, const float*, const float*, float*, float*, void*, size_t, hipStream_t) { return MRI3D_ENOTSUP; }
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int TD = 4, TH = 8, TW = 16;               // output tile (d, h, w)
+constexpr int HD = TD + 2, HH = TH + 2, HW = TW + 2;  // halo tile
+constexpr int HVOX = HD * HH * HW;                   // 1080 voxels
+
+__host__ __device__ constexpr int tap_groups(int CK) { return CK == 16 ? 27 : 14; }
+
+// Bijective XCD-aware remap (cdna_hip_programming.md T1): blocks b and b+8 share an XCD; give each XCD a contiguous
+// range of tiles so that spatial neighbours (which share halo voxels) hit the same L2.
+__device__ __forceinline__ int xcd_remap(int b, int n) {
+    const int q = n >> 3, r = n & 7, xcd = b & 7;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
 }
+
+// ------------------------------------------------------------------ weight packing
+// Wp[chunk][tg][nt][lane][s]:  value = W'(tap, kc, nc) with
+//   nc = nt*16 + (lane & 15)
+//   CK == 16: tap = tg,                 kc = chunk*16 + 4*(lane>>4) + s
+//   CK ==  8: tap = 2*tg + (lane>>5),   kc = chunk*8  + 4*((lane>>4)&1) + s      (tap 27 -> 0)
+//   forward: W'(tap,kc,nc) = W[nc][kc][tap];  dgrad: W'(tap,kc,nc) = W[kc][nc][26 - tap]
+__global__ void pack_w_mfma_kernel(const float* __restrict__ w, float* __restrict__ wp, int Co, int Ci, int dgrad,
+                                   int CK, int NTT, int nchunks) {
+    const int TG = tap_groups(CK);
+    const int total = nchunks * TG * NTT * 256;
+    const int Kc = dgrad ? Co : Ci, Nc = dgrad ? Ci : Co;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        int s = i & 3, lane = (i >> 2) & 63;
+        int t = i >> 8;
+        int nt = t % NTT;
+        t /= NTT;
+        int tg = t % TG;
+        int chunk = t / TG;
+        int nc = nt * 16 + (lane & 15);
+        int tap, kc;
+        if (CK == 16) {
+            tap = tg;
+            kc = chunk * 16 + 4 * (lane >> 4) + s;
+        } else {
+            tap = 2 * tg + (lane >> 5);
+            kc = chunk * 8 + 4 * ((lane >> 4) & 1) + s;
+        }
+        float v = 0.f;
+        if (tap < 27 && nc < Nc && kc < Kc) {
+            v = dgrad ? w[((size_t)kc * Ci + nc) * 27 + (26 - tap)] : w[((size_t)nc * Ci + kc) * 27 + tap];
+        }
+        wp[i] = v;
+    }
+}
+
+// ------------------------------------------------------------------ forward / dgrad kernel
+template <int NT, int CK>
+__global__ void __launch_bounds__(256, 2)
+conv_mfma_fwd_kernel(const float* __restrict__ x, const float* __restrict__ wp, const float* __restrict__ bias,
+                     float* __restrict__ y, int N, int D, int H, int W, int Kc, int x_ld, int Nc, int y_ld, int NTT,
+                     int tilesD, int tilesH, int tilesW, int ntiles) {
+    constexpr int CP = CK;  // LDS voxel pitch in floats
+    constexpr int TG = tap_groups(CK);
+    constexpr int Q = CK / 4;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+
+    int tile = xcd_remap(blockIdx.x, ntiles);
+    const int tw = tile % tilesW;
+    tile /= tilesW;
+    const int th = tile % tilesH;
+    tile /= tilesH;
+    const int td = tile % tilesD;
+    const int n = tile / tilesD;
+    const int w0 = tw * TW, h0 = th * TH, d0 = td * TD;
+    const int nt0 = blockIdx.y * NT;
+
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int li = lane & 15, kq = lane >> 4;
+
+    f32x4 acc[TH][NT];
+#pragma unroll
+    for (int m = 0; m < TH; ++m)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc[m][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int nchunks = Kc / CK;
+    const float* xn = x + (int64_t)n * D * H * W * x_ld;
+    for (int ch = 0; ch < nchunks; ++ch) {
+        __syncthreads();
+        for (int idx = tid; idx < HVOX * Q; idx += 256) {
+            const int q = idx % Q, v = idx / Q;
+            const int wx = v % HW;
+            const int t2 = v / HW;
+            const int hy = t2 % HH, dz = t2 / HH;
+            const int gd = d0 - 1 + dz, gh = h0 - 1 + hy, gw = w0 - 1 + wx;
+            float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
+            if ((unsigned)gd < (unsigned)D && (unsigned)gh < (unsigned)H && (unsigned)gw < (unsigned)W)
+                val = *reinterpret_cast<const float4*>(xn + (((int64_t)gd * H + gh) * W + gw) * x_ld + ch * CK + 4 * q);
+            *reinterpret_cast<float4*>(lds + v * CP + 4 * q) = val;
+        }
+        __syncthreads();
+
+        const float* wt = wp + ((size_t)ch * TG * NTT + nt0) * 256 + lane * 4;
+#pragma unroll
+        for (int tg = 0; tg < TG; ++tg, wt += NTT * 256) {
+            f32x4 bfrag[NT];
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) bfrag[nt] = *reinterpret_cast<const f32x4*>(wt + nt * 256);
+            int aoff;
+            if (CK == 16) {
+                const int kd = tg / 9, kh = (tg / 3) % 3, kw = tg % 3;
+                aoff = (((wv + kd) * HH + kh) * HW + (li + kw)) * CP + 4 * kq;
+            } else {
+                const int ta = 2 * tg, tb = (2 * tg + 1 < 27) ? 2 * tg + 1 : 26;  // tap 27 has zero weights
+                const int oa = ((ta / 9) * HH + (ta / 3) % 3) * HW + ta % 3;
+                const int ob = ((tb / 9) * HH + (tb / 3) % 3) * HW + tb % 3;
+                aoff = ((wv * HH) * HW + li + ((kq >> 1) ? ob : oa)) * CP + 4 * (kq & 1);
+            }
+            f32x4 a[TH];
+#pragma unroll
+            for (int m = 0; m < TH; ++m) a[m] = *reinterpret_cast<const f32x4*>(lds + aoff + m * HW * CP);
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                    for (int m = 0; m < TH; ++m)
+                        acc[m][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[m][s], bfrag[nt][s], acc[m][nt], 0, 0, 0);
+        }
+    }
+
+    // epilogue: lane holds rows (voxels) 4*kq + r, column (channel) li of every 16x16 tile
+    const int od = d0 + wv;
+    if (od < D) {
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            const int co = (nt0 + nt) * 16 + li;
+            if (co >= Nc) continue;
+            const float bv = bias ? bias[co] : 0.f;
+#pragma unroll
+            for (int m = 0; m < TH; ++m) {
+                const int oh = h0 + m;
+                if (oh >= H) continue;
+                float* yrow = y + ((((int64_t)n * D + od) * H + oh) * W) * y_ld + co;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int ow = w0 + 4 * kq + r;
+                    if (ow < W) yrow[(int64_t)ow * y_ld] = acc[m][nt][r] + bv;
+                }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------ host side
+struct MfmaFwdPlan {
+    int CK, NT, NTT, gy, nchunks, tilesD, tilesH, tilesW, ntiles;
+    size_t wp_floats, smem;
+};
+
+static bool mfma_fwd_plan(const Mri3dConvGeom& g, bool dgrad, MfmaFwdPlan& p) {
+    if (!(g.kd == 3 && g.kh == 3 && g.kw == 3 && g.sd == 1 && g.sh == 1 && g.sw == 1 && g.pd == 1 && g.ph == 1 &&
+          g.pw == 1 && g.dd == 1 && g.dh == 1 && g.dw == 1))
+        return false;
+    const int Kc = dgrad ? g.co : g.ci, Nc = dgrad ? g.ci : g.co;
+    const int in_ld = dgrad ? g.y_ld : g.x_ld;
+    if (Kc % 8 != 0 || in_ld % 4 != 0) return false;
+    if (Nc < 8) return false;  // tiny outputs (e.g. 16->2) stay on the direct kernel
+    p.CK = (Kc % 16 == 0) ? 16 : 8;
+    p.NTT = cdiv(Nc, 16);
+    if (p.NTT % 4 == 0) p.NT = 4;
+    else if (p.NTT % 3 == 0) p.NT = 3;
+    else if (p.NTT % 2 == 0) p.NT = 2;
+    else p.NT = 1;
+    if (p.NTT > 4 && p.NT == 1) return false;  // odd large tile counts: not needed by any model here
+    p.gy = p.NTT / p.NT;
+    p.nchunks = Kc / p.CK;
+    p.tilesD = cdiv(g.di, TD);
+    p.tilesH = cdiv(g.hi, TH);
+    p.tilesW = cdiv(g.wi, TW);
+    int64_t nt = (int64_t)g.n * p.tilesD * p.tilesH * p.tilesW;
+    if (nt > 0x7fffffff) return false;
+    p.ntiles = (int)nt;
+    p.wp_floats = (size_t)p.nchunks * tap_groups(p.CK) * p.NTT * 256;
+    p.smem = (size_t)HVOX * p.CK * sizeof(float);
+    return true;
+}
+
+bool conv_mfma_supported(const Mri3dConvGeom& g, int pass) {
+    MfmaFwdPlan p;
+    if (pass == MRI3D_PASS_FWD) return mfma_fwd_plan(g, false, p);
+    if (pass == MRI3D_PASS_DGRAD) return mfma_fwd_plan(g, true, p);
+    return false;
+}
+
+size_t conv_mfma_workspace_bytes(const Mri3dConvGeom& g, int pass) {
+    MfmaFwdPlan p;
+    if (pass == MRI3D_PASS_FWD && mfma_fwd_plan(g, false, p)) return p.wp_floats * sizeof(float);
+    if (pass == MRI3D_PASS_DGRAD && mfma_fwd_plan(g, true, p)) return p.wp_floats * sizeof(float);
+    return 0;
+}
+
+template <int NT, int CK>
+static void launch_mfma_fwd(const MfmaFwdPlan& p, const float* in, const float* wp, const float* bias, float* out, int N,
+                            int D, int H, int W, int Kc, int in_ld, int Nc, int out_ld, hipStream_t s) {
+    auto kern = conv_mfma_fwd_kernel<NT, CK>;
+    if (p.smem > 64 * 1024)
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)p.smem);
+    hipLaunchKernelGGL(kern, dim3(p.ntiles, p.gy), dim3(256), p.smem, s, in, wp, bias, out, N, D, H, W, Kc, in_ld, Nc,
+                       out_ld, p.NTT, p.tilesD, p.tilesH, p.tilesW, p.ntiles);
+}
+
+static int run_mfma_fwd(const Mri3dConvGeom& g, bool dgrad, const float* in, const float* w, const float* bias,
+                        float* out, void* ws, size_t ws_bytes, hipStream_t s) {
+    MfmaFwdPlan p;
+    MRI3D_REQUIRE(mfma_fwd_plan(g, dgrad, p), MRI3D_ENOTSUP, "conv3d(mfma): unsupported geometry");
+    MRI3D_REQUIRE(ws && ws_bytes >= p.wp_floats * sizeof(float), MRI3D_EWORKSPACE, "conv3d(mfma): workspace %zu < %zu",
+                  ws_bytes, p.wp_floats * sizeof(float));
+    MRI3D_REQUIRE((reinterpret_cast<uintptr_t>(in) & 15) == 0 && (reinterpret_cast<uintptr_t>(ws) & 15) == 0,
+                  MRI3D_EINVAL, "conv3d(mfma): input/workspace must be 16-byte aligned");
+    float* wp = static_cast<float*>(ws);
+    const int Kc = dgrad ? g.co : g.ci, Nc = dgrad ? g.ci : g.co;
+    const int in_ld = dgrad ? g.y_ld : g.x_ld, out_ld = dgrad ? g.x_ld : g.y_ld;
+    int total = (int)p.wp_floats;
+    hipLaunchKernelGGL(pack_w_mfma_kernel, dim3(std::min(cdiv(total, 256), 2048)), dim3(256), 0, s, w, wp, g.co, g.ci,
+                       dgrad ? 1 : 0, p.CK, p.NTT, p.nchunks);
+#define MRI3D_FWD_CASE(NTv, CKv)                                                                                      \
+    if (p.NT == NTv && p.CK == CKv)                                                                                   \
+        launch_mfma_fwd<NTv, CKv>(p, in, wp, bias, out, g.n, g.di, g.hi, g.wi, Kc, in_ld, Nc, out_ld, s);
+    MRI3D_FWD_CASE(1, 16)
+    MRI3D_FWD_CASE(2, 16)
+    MRI3D_FWD_CASE(3, 16)
+    MRI3D_FWD_CASE(4, 16)
+    MRI3D_FWD_CASE(1, 8)
+    MRI3D_FWD_CASE(2, 8)
+    MRI3D_FWD_CASE(3, 8)
+    MRI3D_FWD_CASE(4, 8)
+#undef MRI3D_FWD_CASE
+    return check_launch(dgrad ? "conv3d_dgrad(mfma)" : "conv3d_fwd(mfma)");
+}
+
+int conv_mfma_fwd(const Mri3dConvGeom& g, const float* x, const float* w, const float* bias, float* y, void* ws,
+                  size_t ws_bytes, hipStream_t s) {
+    return run_mfma_fwd(g, false, x, w, bias, y, ws, ws_bytes, s);
+}
+
+int conv_mfma_dgrad(const Mri3dConvGeom& g, const float* dy, const float* w, const float* bias, float* dx, void* ws,
+                    size_t ws_bytes, hipStream_t s) {
+    return run_mfma_fwd(g, true, dy, w, bias, dx, ws, ws_bytes, s);
+}
+
+int conv_mfma_wgrad(const Mri3dConvGeom&, const float*, const float*, float*, float*, void*, size_t, hipStream_t) {
+    set_error("conv3d_wgrad(mfma): not implemented");
+    return MRI3D_ENOTSUP;
+}
+
+}  // namespace mri3d
