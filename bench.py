@@ -149,7 +149,7 @@ def main():
         roofline = {"bound": bound, "achieved": round(achieved, 3), "peak": peak, "unit": unit,
                     "frac": round(achieved / peak, 4), "traffic": None, "kernel": dom_tag,
                     "avg_launch_ms": round(avg_s * 1e3, 4), "share_of_timed_ops": round(dom["ms"] / total_ms, 4)}
-        top = sorted(agg.items(), key=lambda kv: -kv[1]["ms"])[:12]
+        top = sorted(agg.items(), key=lambda kv: -kv[1]["ms"])[:int(os.environ.get("MRI3D_BENCH_TOP", "12"))]
         sys.stderr.write("per-operator device time over %d steps (events on the launch stream):\n" % args.steps)
         for tag, a in top:
             w = a["work"] or {}

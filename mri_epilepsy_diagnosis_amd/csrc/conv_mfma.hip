@@ -205,20 +205,6 @@ static bool mfma_fwd_plan(const Mri3dConvGeom& g, bool dgrad, MfmaFwdPlan& p) {
     return true;
 }
 
-bool conv_mfma_supported(const Mri3dConvGeom& g, int pass) {
-    MfmaFwdPlan p;
-    if (pass == MRI3D_PASS_FWD) return mfma_fwd_plan(g, false, p);
-    if (pass == MRI3D_PASS_DGRAD) return mfma_fwd_plan(g, true, p);
-    return false;
-}
-
-size_t conv_mfma_workspace_bytes(const Mri3dConvGeom& g, int pass) {
-    MfmaFwdPlan p;
-    if (pass == MRI3D_PASS_FWD && mfma_fwd_plan(g, false, p)) return p.wp_floats * sizeof(float);
-    if (pass == MRI3D_PASS_DGRAD && mfma_fwd_plan(g, true, p)) return p.wp_floats * sizeof(float);
-    return 0;
-}
-
 template <int NT, int CK>
 static void launch_mfma_fwd(const MfmaFwdPlan& p, const float* in, const float* wp, const float* bias, float* out, int N,
                             int D, int H, int W, int Kc, int in_ld, int Nc, int out_ld, hipStream_t s) {
@@ -269,9 +255,274 @@ int conv_mfma_dgrad(const Mri3dConvGeom& g, const float* dy, const float* w, con
     return run_mfma_fwd(g, true, dy, w, bias, dx, ws, ws_bytes, s);
 }
 
-int conv_mfma_wgrad(const Mri3dConvGeom&, const float*, const float*, float*, float*, void*, size_t, hipStream_t) {
-    set_error("conv3d_wgrad(mfma): not implemented");
-    return MRI3D_ENOTSUP;
+// ================================================================== weight gradient
+// GEMM view: dW(tap, ci; co) = sum over voxels.  One MFMA 16x16x4 takes A = X[4 voxels][16 rows] and B = dY[4 voxels][16 co]:
+//   lane l supplies A[row = l&15][k = l>>4] and B[k = l>>4][col = l&15]; the 4 voxels of a k-step are consecutive in W.
+//   rows of an M-tile:  CK=16: 16 input channels of one tap        (27 tap groups)
+//                       CK= 8: 2 taps x 8 channels                 (14 tap groups, tap 27 = padding)
+//                       CK= 1: 16 taps x the single input channel  ( 2 tap groups, taps 27..31 = padding)
+// A workgroup (4 waves) is persistent over a contiguous range of 2x8x16-voxel tiles; it stages the X halo chunk and the
+// dY tile (16 output channels) in LDS, each wave sweeps one quarter of the tile's voxels and keeps ALL tap groups of
+// its (ci-tile, co-tile) pair in registers (27 x 4 VGPRs), so X and dY are read from LDS once per MFMA and from HBM/L2
+// once per tile.  dbias rides along as one more accumulator fed with A = 1.  Partials are combined across the 4 waves
+// through LDS in a fixed order, written once per workgroup, and summed by wgrad_mfma_reduce_kernel in a fixed order
+// (deterministic: no float atomics).
+constexpr int WTD = 2, WTH = 8, WTW = 16;
+constexpr int WHD = WTD + 2, WHH = WTH + 2, WHW = WTW + 2;
+constexpr int WHVOX = WHD * WHH * WHW;   // 720
+constexpr int WVOX = WTD * WTH * WTW;    // 256
+
+__host__ __device__ constexpr int wg_tap_groups(int CK) { return CK == 16 ? 27 : (CK == 8 ? 14 : 2); }
+
+template <int CK>
+__device__ __forceinline__ int wg_tap_offset(int tap) {  // halo-voxel offset of a tap (clamped to tap 26 for padding)
+    const int t = tap < 27 ? tap : 26;
+    return ((t / 9) * WHH + (t / 3) % 3) * WHW + t % 3;
+}
+
+template <int CK, bool BIAS>
+__global__ void __launch_bounds__(256, 2)
+conv_mfma_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ part, int N, int D,
+                       int H, int W, int Ci, int x_ld, int Co, int y_ld, int tilesD, int tilesH, int tilesW, int ntiles) {
+    constexpr int TG = wg_tap_groups(CK);
+    constexpr int TGA = TG + (BIAS ? 1 : 0);
+    constexpr int CP = CK;           // X tile voxel pitch (floats)
+    constexpr int XV = CK >= 4 ? 4 : 1;  // staging vector width
+    constexpr int XQ = CK / XV;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* xs = lds;                              // [WHVOX][CP]
+    float* dys = lds + ((WHVOX * CP + 3) & ~3);   // [WVOX][16]
+
+    const int cit = blockIdx.y, cob = blockIdx.z;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int li = lane & 15, kq = lane >> 4;
+    const int dsel = wv >> 1, hsel = wv & 1;
+
+    f32x4 acc[TGA];
+#pragma unroll
+    for (int t = 0; t < TGA; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // per-lane A offsets that do not depend on the voxel
+    int lane_aoff[TG];
+#pragma unroll
+    for (int tg = 0; tg < TG; ++tg) {
+        if (CK == 16) lane_aoff[tg] = wg_tap_offset<CK>(tg) * CP + li;
+        else if (CK == 8) lane_aoff[tg] = wg_tap_offset<CK>(2 * tg + (li >> 3)) * CP + (li & 7);
+        else lane_aoff[tg] = wg_tap_offset<CK>(16 * tg + li);
+    }
+
+    const int P = gridDim.x;
+    const int t_lo = (int)(((int64_t)ntiles * blockIdx.x) / P), t_hi = (int)(((int64_t)ntiles * (blockIdx.x + 1)) / P);
+    for (int tile = t_lo; tile < t_hi; ++tile) {
+        int tt = tile;
+        const int tw = tt % tilesW;
+        tt /= tilesW;
+        const int th = tt % tilesH;
+        tt /= tilesH;
+        const int td = tt % tilesD;
+        const int n = tt / tilesD;
+        const int w0 = tw * WTW, h0 = th * WTH, d0 = td * WTD;
+        const float* xn = x + (int64_t)n * D * H * W * x_ld + cit * CK;
+        const float* dn = dy + (int64_t)n * D * H * W * y_ld + cob * 16;
+
+        __syncthreads();
+        for (int idx = tid; idx < WHVOX * XQ; idx += 256) {
+            const int q = idx % XQ, v = idx / XQ;
+            const int wx = v % WHW;
+            const int t2 = v / WHW;
+            const int hy = t2 % WHH, dz = t2 / WHH;
+            const int gd = d0 - 1 + dz, gh = h0 - 1 + hy, gw = w0 - 1 + wx;
+            const bool ok = (unsigned)gd < (unsigned)D && (unsigned)gh < (unsigned)H && (unsigned)gw < (unsigned)W;
+            const float* src = xn + (((int64_t)gd * H + gh) * W + gw) * x_ld + XV * q;
+            if (XV == 4) {
+                float4 val = ok ? *reinterpret_cast<const float4*>(src) : make_float4(0.f, 0.f, 0.f, 0.f);
+                *reinterpret_cast<float4*>(xs + v * CP + 4 * q) = val;
+            } else {
+                xs[v * CP + q] = ok ? *src : 0.f;
+            }
+        }
+        for (int idx = tid; idx < WVOX * 4; idx += 256) {
+            const int q = idx & 3, v = idx >> 2;
+            const int wx = v % WTW;
+            const int t2 = v / WTW;
+            const int hy = t2 % WTH, dz = t2 / WTH;
+            const int gd = d0 + dz, gh = h0 + hy, gw = w0 + wx;
+            const bool ok = gd < D && gh < H && gw < W;
+            const float* src = dn + (((int64_t)gd * H + gh) * W + gw) * y_ld + 4 * q;
+            float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
+            const int cbase = cob * 16 + 4 * q;
+            if (ok) {
+                if (cbase + 3 < Co && (y_ld & 3) == 0) {
+                    val = *reinterpret_cast<const float4*>(src);
+                } else {
+                    if (cbase + 0 < Co) val.x = src[0];
+                    if (cbase + 1 < Co) val.y = src[1];
+                    if (cbase + 2 < Co) val.z = src[2];
+                    if (cbase + 3 < Co) val.w = src[3];
+                }
+            }
+            *reinterpret_cast<float4*>(dys + v * 16 + 4 * q) = val;
+        }
+        __syncthreads();
+
+#pragma unroll 1
+        for (int hr = 0; hr < 4; ++hr) {
+            const int hy = hsel * 4 + hr;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const int wx = ks * 4 + kq;
+                const float b = dys[((dsel * WTH + hy) * WTW + wx) * 16 + li];
+                const float* abase = xs + ((dsel * WHH + hy) * WHW + wx) * CP;
+#pragma unroll
+                for (int tg = 0; tg < TG; ++tg) {
+                    const float a = abase[lane_aoff[tg]];
+                    acc[tg] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc[tg], 0, 0, 0);
+                }
+                if (BIAS) acc[TG] = __builtin_amdgcn_mfma_f32_16x16x4f32(1.0f, b, acc[TG], 0, 0, 0);
+            }
+        }
+    }
+
+    // combine the 4 waves in a fixed order through LDS, then one partial per workgroup
+    __syncthreads();
+    float* red = lds;  // [TGA][256]
+    for (int w = 0; w < 4; ++w) {
+        if (wv == w) {
+#pragma unroll
+            for (int t = 0; t < TGA; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int o = t * 256 + (4 * kq + r) * 16 + li;
+                    red[o] = (w == 0) ? acc[t][r] : red[o] + acc[t][r];
+                }
+        }
+        __syncthreads();
+    }
+    float* out = part + (((size_t)blockIdx.x * gridDim.y + cit) * gridDim.z + cob) * (TGA * 256);
+    for (int i = tid; i < TGA * 256; i += 256) out[i] = red[i];
+}
+
+// dw[co][ci][tap] = sum_p part[p][cit][cob][tg][row][col]   (+ dbias[co] from the extra accumulator of cit == 0)
+__global__ void wgrad_mfma_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw, float* __restrict__ dbias,
+                                         int P, int CIT, int COB, int CK, int TG, int TGA, int Ci, int Co) {
+    const int total = Co * Ci * 27;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t pstride = (size_t)CIT * COB * TGA * 256;
+    if (i < total) {
+        const int tap = i % 27, ci = (i / 27) % Ci, co = i / (27 * Ci);
+        int cit, tg, row;
+        if (CK == 16) { cit = ci >> 4; tg = tap; row = ci & 15; }
+        else if (CK == 8) { cit = ci >> 3; tg = tap >> 1; row = (tap & 1) * 8 + (ci & 7); }
+        else { cit = ci; tg = tap >> 4; row = tap & 15; }
+        const int cob = co >> 4, col = co & 15;
+        const float* p = part + (((size_t)cit * COB + cob) * TGA + tg) * 256 + row * 16 + col;
+        double s = 0.0;
+        for (int q = 0; q < P; ++q) s += (double)p[q * pstride];
+        dw[i] = (float)s;
+    }
+    if (dbias != nullptr && i < Co) {
+        const int cob = i >> 4, col = i & 15;
+        const float* p = part + (((size_t)0 * COB + cob) * TGA + TG) * 256 + col;  // row 0 of the bias accumulator
+        double s = 0.0;
+        for (int q = 0; q < P; ++q) s += (double)p[q * pstride];
+        dbias[i] = (float)s;
+    }
+}
+
+struct MfmaWgradPlan {
+    int CK, CIT, COB, TG, P, tilesD, tilesH, tilesW, ntiles;
+    size_t part_floats, smem;
+};
+
+static bool mfma_wgrad_plan(const Mri3dConvGeom& g, MfmaWgradPlan& p) {
+    if (!(g.kd == 3 && g.kh == 3 && g.kw == 3 && g.sd == 1 && g.sh == 1 && g.sw == 1 && g.pd == 1 && g.ph == 1 &&
+          g.pw == 1 && g.dd == 1 && g.dh == 1 && g.dw == 1))
+        return false;
+    if (g.ci % 16 == 0) p.CK = 16;
+    else if (g.ci % 8 == 0) p.CK = 8;
+    else if (g.ci == 1) p.CK = 1;
+    else return false;
+    if (p.CK >= 4 && g.x_ld % 4 != 0) return false;
+    p.CIT = g.ci / p.CK;
+    p.COB = cdiv(g.co, 16);
+    p.TG = wg_tap_groups(p.CK);
+    p.tilesD = cdiv(g.di, WTD);
+    p.tilesH = cdiv(g.hi, WTH);
+    p.tilesW = cdiv(g.wi, WTW);
+    int64_t nt = (int64_t)g.n * p.tilesD * p.tilesH * p.tilesW;
+    if (nt > 0x7fffffff) return false;
+    p.ntiles = (int)nt;
+    int pairs = p.CIT * p.COB;
+    if (pairs > 65535) return false;
+    int P = 512 / pairs;  // ~2 resident workgroups per CU in total
+    if (P < 1) P = 1;
+    if (P > p.ntiles) P = p.ntiles;
+    p.P = P;
+    p.part_floats = (size_t)P * pairs * (p.TG + 1) * 256;
+    size_t xs = ((size_t)WHVOX * p.CK + 3) & ~(size_t)3;
+    size_t red = (size_t)(p.TG + 1) * 256;
+    size_t tile_floats = xs + (size_t)WVOX * 16;
+    p.smem = (tile_floats > red ? tile_floats : red) * sizeof(float);
+    return true;
+}
+
+bool conv_mfma_supported(const Mri3dConvGeom& g, int pass) {
+    MfmaFwdPlan p;
+    MfmaWgradPlan q;
+    if (pass == MRI3D_PASS_FWD) return mfma_fwd_plan(g, false, p);
+    if (pass == MRI3D_PASS_DGRAD) return mfma_fwd_plan(g, true, p);
+    if (pass == MRI3D_PASS_WGRAD) return mfma_wgrad_plan(g, q);
+    return false;
+}
+
+size_t conv_mfma_workspace_bytes(const Mri3dConvGeom& g, int pass) {
+    MfmaFwdPlan p;
+    MfmaWgradPlan q;
+    if (pass == MRI3D_PASS_FWD && mfma_fwd_plan(g, false, p)) return p.wp_floats * sizeof(float);
+    if (pass == MRI3D_PASS_DGRAD && mfma_fwd_plan(g, true, p)) return p.wp_floats * sizeof(float);
+    if (pass == MRI3D_PASS_WGRAD && mfma_wgrad_plan(g, q)) return q.part_floats * sizeof(float);
+    return 0;
+}
+
+template <int CK>
+static void launch_mfma_wgrad(const MfmaWgradPlan& p, const Mri3dConvGeom& g, const float* x, const float* dy,
+                              float* part, bool bias, hipStream_t s) {
+    dim3 grid(p.P, p.CIT, p.COB);
+    if (bias) {
+        auto kern = conv_mfma_wgrad_kernel<CK, true>;
+        if (p.smem > 64 * 1024)
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.smem);
+        hipLaunchKernelGGL(kern, grid, dim3(256), p.smem, s, x, dy, part, g.n, g.di, g.hi, g.wi, g.ci, g.x_ld, g.co,
+                           g.y_ld, p.tilesD, p.tilesH, p.tilesW, p.ntiles);
+    } else {
+        auto kern = conv_mfma_wgrad_kernel<CK, false>;
+        if (p.smem > 64 * 1024)
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.smem);
+        hipLaunchKernelGGL(kern, grid, dim3(256), p.smem, s, x, dy, part, g.n, g.di, g.hi, g.wi, g.ci, g.x_ld, g.co,
+                           g.y_ld, p.tilesD, p.tilesH, p.tilesW, p.ntiles);
+    }
+}
+
+int conv_mfma_wgrad(const Mri3dConvGeom& g, const float* x, const float* dy, float* dw, float* dbias, void* ws,
+                    size_t ws_bytes, hipStream_t s) {
+    MfmaWgradPlan p;
+    MRI3D_REQUIRE(mfma_wgrad_plan(g, p), MRI3D_ENOTSUP, "conv3d_wgrad(mfma): unsupported geometry");
+    MRI3D_REQUIRE(ws && ws_bytes >= p.part_floats * sizeof(float), MRI3D_EWORKSPACE,
+                  "conv3d_wgrad(mfma): workspace %zu < %zu", ws_bytes, p.part_floats * sizeof(float));
+    MRI3D_REQUIRE(((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(dy)) & 15) == 0, MRI3D_EINVAL,
+                  "conv3d_wgrad(mfma): x/dy must be 16-byte aligned");
+    float* part = static_cast<float*>(ws);
+    const bool bias = dbias != nullptr;
+    // the kernel template always reserves the bias accumulator slot in the partial layout (TGA = TG + 1) only when BIAS;
+    // keep the layout uniform by always running the BIAS variant when dbias is requested.
+    if (p.CK == 16) launch_mfma_wgrad<16>(p, g, x, dy, part, bias, s);
+    else if (p.CK == 8) launch_mfma_wgrad<8>(p, g, x, dy, part, bias, s);
+    else launch_mfma_wgrad<1>(p, g, x, dy, part, bias, s);
+    const int TGA = p.TG + (bias ? 1 : 0);
+    const int total = g.co * g.ci * 27;
+    hipLaunchKernelGGL(wgrad_mfma_reduce_kernel, dim3(cdiv(std::max(total, g.co), 256)), dim3(256), 0, s, part, dw, dbias,
+                       p.P, p.CIT, p.COB, p.CK, p.TG, TGA, g.ci, g.co);
+    return check_launch("conv3d_wgrad(mfma)");
 }
 
 }  // namespace mri3d
