@@ -32,6 +32,14 @@ int conv_mfma_dgrad(const Mri3dConvGeom& g, const float* dy, const float* w, con
 int conv_mfma_wgrad(const Mri3dConvGeom& g, const float* x, const float* dy, float* dw, float* dbias, void* ws,
                     size_t ws_bytes, hipStream_t s);
 
+// conv_pointwise.hip
+bool conv_pointwise_supported(const Mri3dConvGeom& g, int pass);
+size_t conv_pointwise_workspace_bytes(const Mri3dConvGeom& g, int pass);
+int conv_pointwise_dgrad(const Mri3dConvGeom& g, const float* dy, const float* w, const float* bias, float* dx,
+                         hipStream_t s);
+int conv_pointwise_wgrad(const Mri3dConvGeom& g, const float* x, const float* dy, float* dw, float* dbias, void* ws,
+                         size_t ws_bytes, hipStream_t s);
+
 static int conv_check(const Mri3dConvGeom* g, const char* who) {
     MRI3D_REQUIRE(g != nullptr, MRI3D_EINVAL, "%s: null geometry", who);
     MRI3D_REQUIRE(g->dtype == MRI3D_F32, MRI3D_ENOTSUP, "%s: only MRI3D_F32 is implemented (dtype=%d)", who, g->dtype);
@@ -63,7 +71,9 @@ extern "C" size_t mri3d_conv3d_workspace_bytes(const Mri3dConvGeom* g, int pass)
     if (!g) return 0;
     size_t a = conv_generic_workspace_bytes(*g, pass);
     size_t b = conv_mfma_supported(*g, pass) ? conv_mfma_workspace_bytes(*g, pass) : 0;
-    return align_up(a > b ? a : b, 256);
+    size_t c = conv_pointwise_supported(*g, pass) ? conv_pointwise_workspace_bytes(*g, pass) : 0;
+    a = a > b ? a : b;
+    return align_up(a > c ? a : c, 256);
 }
 
 extern "C" int mri3d_conv3d_fwd(const Mri3dConvGeom* g, const void* x, const void* w, const void* bias, void* y,
@@ -83,6 +93,9 @@ extern "C" int mri3d_conv3d_dgrad(const Mri3dConvGeom* g, const void* dy, const 
     if (rc) return rc;
     MRI3D_REQUIRE(dy && w && dx, MRI3D_EINVAL, "conv3d_dgrad: null pointer");
     hipStream_t s = static_cast<hipStream_t>(stream);
+    if (conv_pointwise_supported(*g, MRI3D_PASS_DGRAD) && (reinterpret_cast<uintptr_t>(dx) & 15) == 0 &&
+        (reinterpret_cast<uintptr_t>(w) & 15) == 0 && (reinterpret_cast<uintptr_t>(bias) & 15) == 0)
+        return conv_pointwise_dgrad(*g, (const float*)dy, (const float*)w, (const float*)bias, (float*)dx, s);
     if (conv_mfma_supported(*g, MRI3D_PASS_DGRAD))
         return conv_mfma_dgrad(*g, (const float*)dy, (const float*)w, (const float*)bias, (float*)dx, workspace, ws_bytes, s);
     return conv_generic_dgrad(*g, (const float*)dy, (const float*)w, (const float*)bias, (float*)dx, workspace, ws_bytes, s);
@@ -94,6 +107,8 @@ extern "C" int mri3d_conv3d_wgrad(const Mri3dConvGeom* g, const void* x, const v
     if (rc) return rc;
     MRI3D_REQUIRE(x && dy && dw, MRI3D_EINVAL, "conv3d_wgrad: null pointer");
     hipStream_t s = static_cast<hipStream_t>(stream);
+    if (conv_pointwise_supported(*g, MRI3D_PASS_WGRAD) && (reinterpret_cast<uintptr_t>(x) & 15) == 0)
+        return conv_pointwise_wgrad(*g, (const float*)x, (const float*)dy, (float*)dw, (float*)dbias, workspace, ws_bytes, s);
     if (conv_mfma_supported(*g, MRI3D_PASS_WGRAD))
         return conv_mfma_wgrad(*g, (const float*)x, (const float*)dy, (float*)dw, (float*)dbias, workspace, ws_bytes, s);
     return conv_generic_wgrad(*g, (const float*)x, (const float*)dy, (float*)dw, (float*)dbias, workspace, ws_bytes, s);

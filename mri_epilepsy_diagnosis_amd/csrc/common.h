@@ -48,6 +48,12 @@ __device__ __forceinline__ float wave_sum(float v) {
     return v;
 }
 
+__device__ __forceinline__ double wave_sum_d(double v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
 __device__ __forceinline__ float apply_act(float v, int act, float slope) {
     // act: MRI3D_ACT_*; for PReLU the caller passes alpha as `slope`.
     if (act == MRI3D_ACT_RELU) return v > 0.f ? v : 0.f;

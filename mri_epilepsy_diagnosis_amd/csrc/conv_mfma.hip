@@ -403,30 +403,40 @@ conv_mfma_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ dy
 }
 
 // dw[co][ci][tap] = sum_p part[p][cit][cob][tg][row][col]   (+ dbias[co] from the extra accumulator of cit == 0)
-__global__ void wgrad_mfma_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw, float* __restrict__ dbias,
-                                         int P, int CIT, int COB, int CK, int TG, int TGA, int Ci, int Co) {
-    const int total = Co * Ci * 27;
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    const size_t pstride = (size_t)CIT * COB * TGA * 256;
-    if (i < total) {
-        const int tap = i % 27, ci = (i / 27) % Ci, co = i / (27 * Ci);
-        int cit, tg, row;
-        if (CK == 16) { cit = ci >> 4; tg = tap; row = ci & 15; }
-        else if (CK == 8) { cit = ci >> 3; tg = tap >> 1; row = (tap & 1) * 8 + (ci & 7); }
-        else { cit = ci; tg = tap >> 4; row = tap & 15; }
-        const int cob = co >> 4, col = co & 15;
-        const float* p = part + (((size_t)cit * COB + cob) * TGA + tg) * 256 + row * 16 + col;
-        double s = 0.0;
-        for (int q = 0; q < P; ++q) s += (double)p[q * pstride];
-        dw[i] = (float)s;
+// Threads walk the partial layout itself (64 consecutive elements per wave => coalesced 256-byte reads of every
+// partial), 4 partial-lanes per element combined through LDS in double; the (tiny) result is scattered into torch's
+// (Co, Ci, 3,3,3) layout.
+__global__ void __launch_bounds__(256)
+wgrad_mfma_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw, float* __restrict__ dbias, int P,
+                         int CIT, int COB, int CK, int TG, int TGA, int Ci, int Co) {
+    __shared__ double red[256];
+    const int el = threadIdx.x & 63, ql = threadIdx.x >> 6;
+    const int nelem = CIT * COB * TGA * 256;
+    const int e = blockIdx.x * 64 + el;
+    const size_t pstride = (size_t)nelem;
+    double s = 0.0;
+    if (e < nelem)
+        for (int q = ql; q < P; q += 4) s += (double)part[(size_t)q * pstride + e];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    if (ql != 0 || e >= nelem) return;
+    s = red[el] + red[64 + el] + red[128 + el] + red[192 + el];
+    const int col = e & 15, row = (e >> 4) & 15;
+    int t = e >> 8;
+    const int tg = t % TGA;
+    t /= TGA;
+    const int cob = t % COB, cit = t / COB;
+    const int co = cob * 16 + col;
+    if (co >= Co) return;
+    if (tg == TG) {  // bias accumulator (all rows equal): take row 0 of the first ci tile
+        if (dbias != nullptr && cit == 0 && row == 0) dbias[co] = (float)s;
+        return;
     }
-    if (dbias != nullptr && i < Co) {
-        const int cob = i >> 4, col = i & 15;
-        const float* p = part + (((size_t)0 * COB + cob) * TGA + TG) * 256 + col;  // row 0 of the bias accumulator
-        double s = 0.0;
-        for (int q = 0; q < P; ++q) s += (double)p[q * pstride];
-        dbias[i] = (float)s;
-    }
+    int ci, tap;
+    if (CK == 16) { ci = cit * 16 + row; tap = tg; }
+    else if (CK == 8) { ci = cit * 8 + (row & 7); tap = 2 * tg + (row >> 3); }
+    else { ci = cit; tap = 16 * tg + row; }
+    if (tap < 27 && ci < Ci) dw[((size_t)co * Ci + ci) * 27 + tap] = (float)s;
 }
 
 struct MfmaWgradPlan {
@@ -519,9 +529,9 @@ int conv_mfma_wgrad(const Mri3dConvGeom& g, const float* x, const float* dy, flo
     else if (p.CK == 8) launch_mfma_wgrad<8>(p, g, x, dy, part, bias, s);
     else launch_mfma_wgrad<1>(p, g, x, dy, part, bias, s);
     const int TGA = p.TG + (bias ? 1 : 0);
-    const int total = g.co * g.ci * 27;
-    hipLaunchKernelGGL(wgrad_mfma_reduce_kernel, dim3(cdiv(std::max(total, g.co), 256)), dim3(256), 0, s, part, dw, dbias,
-                       p.P, p.CIT, p.COB, p.CK, p.TG, TGA, g.ci, g.co);
+    const int nelem = p.CIT * p.COB * TGA * 256;
+    hipLaunchKernelGGL(wgrad_mfma_reduce_kernel, dim3(cdiv(nelem, 64)), dim3(256), 0, s, part, dw, dbias, p.P, p.CIT,
+                       p.COB, p.CK, p.TG, TGA, g.ci, g.co);
     return check_launch("conv3d_wgrad(mfma)");
 }
 

@@ -1,0 +1,165 @@
+// conv_pointwise.hip — 1x1x1 Conv3d data- and weight-gradient for narrow heads at full resolution: the 16->2
+// classifier of unet.UNet (segmentation/routine.py:346-356 builds it; SURVEY Appendix A.1 `classifier`) and the
+// deep-supervision / localisation 1x1x1 convs of modified_3dunet.py:42-65.  Both passes are pure HBM streams
+// (algorithmic bytes: one read of x and dy, one write of dx); the direct generic kernels spend their time on
+// uncoalesced 4-byte stores and LDS staging instead, so these get their own lane mapping:
+//   dgrad: lane = (voxel, 4-channel quad of dx)   -> every wave stores 1 KiB contiguous
+//   wgrad: lane = (voxel lane, 4-channel quad of x) with a 4 x CO register tile, block-reduced through LDS in double,
+//          one partial per block, fixed-order final sum (deterministic).
+#include "common.h"
+
+namespace mri3d {
+
+__global__ void __launch_bounds__(256)
+pw_dgrad_kernel(const float* __restrict__ dy, const float* __restrict__ w, const float* __restrict__ bias,
+                float* __restrict__ dx, int64_t nvox, int Ci, int Co, int x_ld, int y_ld) {
+    const int QC = Ci >> 2;
+    const int64_t total = nvox * QC;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int q = (int)(i % QC);
+        const int64_t v = i / QC;
+        float4 acc = bias ? *reinterpret_cast<const float4*>(bias + 4 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
+        const float* g = dy + v * y_ld;
+        for (int co = 0; co < Co; ++co) {
+            const float gv = g[co];
+            const float4 wv = *reinterpret_cast<const float4*>(w + (size_t)co * Ci + 4 * q);
+            acc.x = fmaf(gv, wv.x, acc.x);
+            acc.y = fmaf(gv, wv.y, acc.y);
+            acc.z = fmaf(gv, wv.z, acc.z);
+            acc.w = fmaf(gv, wv.w, acc.w);
+        }
+        *reinterpret_cast<float4*>(dx + v * x_ld + 4 * q) = acc;
+    }
+}
+
+constexpr int kPwMaxBlocks = 1024;
+
+// part[blk][co][ci] (+ bias_part[blk][co])
+template <int CO>
+__global__ void __launch_bounds__(256)
+pw_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ dy, double* __restrict__ part,
+                double* __restrict__ bias_part, int64_t nvox, int Ci, int Co, int x_ld, int y_ld) {
+    extern __shared__ __attribute__((aligned(16))) double redd[];  // [256][4*CO + CO]
+    const int QC = Ci >> 2;
+    const int VL = 256 / QC;
+    const int tid = threadIdx.x;
+    const int q = tid % QC, vl = tid / QC;
+    double acc[4][CO], bsum[CO];
+#pragma unroll
+    for (int c = 0; c < CO; ++c) {
+        bsum[c] = 0.0;
+#pragma unroll
+        for (int a = 0; a < 4; ++a) acc[a][c] = 0.0;
+    }
+    if (vl < VL) {
+        for (int64_t v = (int64_t)blockIdx.x * VL + vl; v < nvox; v += (int64_t)gridDim.x * VL) {
+            const float4 xv = *reinterpret_cast<const float4*>(x + v * x_ld + 4 * q);
+            const float* g = dy + v * y_ld;
+#pragma unroll
+            for (int c = 0; c < CO; ++c) {
+                const float gv = c < Co ? g[c] : 0.f;
+                acc[0][c] += (double)(xv.x * gv);
+                acc[1][c] += (double)(xv.y * gv);
+                acc[2][c] += (double)(xv.z * gv);
+                acc[3][c] += (double)(xv.w * gv);
+                if (q == 0) bsum[c] += (double)gv;
+            }
+        }
+    }
+    constexpr int S = 5 * CO;
+#pragma unroll
+    for (int c = 0; c < CO; ++c) {
+#pragma unroll
+        for (int a = 0; a < 4; ++a) redd[tid * S + a * CO + c] = acc[a][c];
+        redd[tid * S + 4 * CO + c] = bsum[c];
+    }
+    __syncthreads();
+    // thread (q, a, c) sums over the VL voxel lanes
+    for (int o = tid; o < QC * 4 * CO; o += 256) {
+        const int c = o % CO, a = (o / CO) & 3, qq = o / (4 * CO);
+        double s = 0.0;
+        for (int l = 0; l < VL; ++l) s += redd[(l * QC + qq) * S + a * CO + c];
+        if (c < Co) part[((size_t)blockIdx.x * Co + c) * Ci + 4 * qq + a] = s;
+    }
+    if (bias_part != nullptr && tid < Co) {
+        double s = 0.0;
+        for (int l = 0; l < VL; ++l) s += redd[(l * QC) * S + 4 * CO + tid];
+        bias_part[(size_t)blockIdx.x * Co + tid] = s;
+    }
+}
+
+__global__ void pw_wgrad_reduce_kernel(const double* __restrict__ part, const double* __restrict__ bias_part,
+                                       float* __restrict__ dw, float* __restrict__ dbias, int nb, int Ci, int Co) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < Co * Ci) {
+        double s = 0.0;
+        for (int b = 0; b < nb; ++b) s += part[(size_t)b * Co * Ci + i];
+        dw[i] = (float)s;
+    }
+    if (dbias != nullptr && i < Co) {
+        double s = 0.0;
+        for (int b = 0; b < nb; ++b) s += bias_part[(size_t)b * Co + i];
+        dbias[i] = (float)s;
+    }
+}
+
+static bool is_pointwise(const Mri3dConvGeom& g) {
+    return g.kd == 1 && g.kh == 1 && g.kw == 1 && g.sd == 1 && g.sh == 1 && g.sw == 1 && g.pd == 0 && g.ph == 0 &&
+           g.pw == 0;
+}
+
+static int pw_blocks(const Mri3dConvGeom& g) {
+    const int64_t nvox = (int64_t)g.n * g.dout * g.ho * g.wo;
+    const int VL = 256 / (g.ci >> 2);
+    int64_t want = cdiv64(nvox, (int64_t)VL * 16);
+    return (int)std::max<int64_t>(1, std::min<int64_t>(want, kPwMaxBlocks));
+}
+
+bool conv_pointwise_supported(const Mri3dConvGeom& g, int pass) {
+    if (!is_pointwise(g) || g.ci % 4 != 0 || g.x_ld % 4 != 0 || g.ci > 256) return false;
+    if (pass == MRI3D_PASS_DGRAD) return g.co <= 16;
+    if (pass == MRI3D_PASS_WGRAD) return g.co <= 8 && g.ci <= 64;
+    return false;
+}
+
+size_t conv_pointwise_workspace_bytes(const Mri3dConvGeom& g, int pass) {
+    if (pass != MRI3D_PASS_WGRAD) return 0;
+    return (size_t)pw_blocks(g) * (g.co * g.ci + g.co) * sizeof(double);
+}
+
+int conv_pointwise_dgrad(const Mri3dConvGeom& g, const float* dy, const float* w, const float* bias, float* dx,
+                         hipStream_t s) {
+    MRI3D_REQUIRE(((reinterpret_cast<uintptr_t>(dx) | reinterpret_cast<uintptr_t>(w) | reinterpret_cast<uintptr_t>(bias)) & 15) == 0,
+                  MRI3D_EINVAL, "conv3d_dgrad(pointwise): dx/w/bias must be 16-byte aligned");
+    const int64_t nvox = (int64_t)g.n * g.di * g.hi * g.wi;
+    hipLaunchKernelGGL(pw_dgrad_kernel, dim3(stream_grid(nvox * (g.ci >> 2), 256)), dim3(256), 0, s, dy, w, bias, dx, nvox,
+                       g.ci, g.co, g.x_ld, g.y_ld);
+    return check_launch("conv3d_dgrad(pointwise)");
+}
+
+int conv_pointwise_wgrad(const Mri3dConvGeom& g, const float* x, const float* dy, float* dw, float* dbias, void* ws,
+                         size_t ws_bytes, hipStream_t s) {
+    const int nb = pw_blocks(g);
+    const size_t need = conv_pointwise_workspace_bytes(g, MRI3D_PASS_WGRAD);
+    MRI3D_REQUIRE(ws && ws_bytes >= need, MRI3D_EWORKSPACE, "conv3d_wgrad(pointwise): workspace %zu < %zu", ws_bytes, need);
+    MRI3D_REQUIRE((reinterpret_cast<uintptr_t>(x) & 15) == 0 && (reinterpret_cast<uintptr_t>(ws) & 7) == 0, MRI3D_EINVAL,
+                  "conv3d_wgrad(pointwise): x must be 16-byte aligned");
+    double* part = static_cast<double*>(ws);
+    double* bias_part = dbias ? part + (size_t)nb * g.co * g.ci : nullptr;
+    const int64_t nvox = (int64_t)g.n * g.di * g.hi * g.wi;
+    const int CO = g.co <= 2 ? 2 : (g.co <= 4 ? 4 : 8);
+    const size_t smem = (size_t)256 * 5 * CO * sizeof(double);
+    if (CO == 2)
+        hipLaunchKernelGGL(pw_wgrad_kernel<2>, dim3(nb), dim3(256), smem, s, x, dy, part, bias_part, nvox, g.ci, g.co, g.x_ld, g.y_ld);
+    else if (CO == 4)
+        hipLaunchKernelGGL(pw_wgrad_kernel<4>, dim3(nb), dim3(256), smem, s, x, dy, part, bias_part, nvox, g.ci, g.co, g.x_ld, g.y_ld);
+    else {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(pw_wgrad_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        hipLaunchKernelGGL(pw_wgrad_kernel<8>, dim3(nb), dim3(256), smem, s, x, dy, part, bias_part, nvox, g.ci, g.co, g.x_ld, g.y_ld);
+    }
+    hipLaunchKernelGGL(pw_wgrad_reduce_kernel, dim3(cdiv(g.co * g.ci, 256)), dim3(256), 0, s, part, bias_part, dw, dbias, nb,
+                       g.ci, g.co);
+    return check_launch("conv3d_wgrad(pointwise)");
+}
+
+}  // namespace mri3d

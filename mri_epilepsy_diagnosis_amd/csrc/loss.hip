@@ -32,15 +32,15 @@ __device__ __forceinline__ void softmax_c(const float* z, float (&p)[C]) {
 // part[n][blk][c][3] = (tp, sum_p, sum_g)
 template <int C>
 __global__ void __launch_bounds__(256)
-dice_fwd_kernel(const float* __restrict__ logits, const float* __restrict__ target, float* __restrict__ part,
+dice_fwd_kernel(const float* __restrict__ logits, const float* __restrict__ target, double* __restrict__ part,
                 int64_t vox, int ct, int x_ld, int t_ld) {
-    __shared__ float red[4][C * 3];
+    __shared__ double red[4][C * 3];
     const int n = blockIdx.y;
     const float* zn = logits + (int64_t)n * vox * x_ld;
     const float* tn = target + (int64_t)n * vox * t_ld;
-    float tp[C], sp[C], sg[C];
+    double tp[C], sp[C], sg[C];  // torch's CPU reductions (the oracle's arithmetic) accumulate float sums in double
 #pragma unroll
-    for (int j = 0; j < C; ++j) { tp[j] = 0.f; sp[j] = 0.f; sg[j] = 0.f; }
+    for (int j = 0; j < C; ++j) { tp[j] = 0.0; sp[j] = 0.0; sg[j] = 0.0; }
     for (int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; v < vox; v += (int64_t)gridDim.x * blockDim.x) {
         float z[C], p[C];
 #pragma unroll
@@ -49,37 +49,37 @@ dice_fwd_kernel(const float* __restrict__ logits, const float* __restrict__ targ
 #pragma unroll
         for (int j = 0; j < C; ++j) {
             float g = tn[v * t_ld + (ct == 1 ? 0 : j)];
-            tp[j] = fmaf(p[j], g, tp[j]);
-            sp[j] += p[j];
-            sg[j] += g;
+            tp[j] += (double)(p[j] * g);
+            sp[j] += (double)p[j];
+            sg[j] += (double)g;
         }
     }
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
 #pragma unroll
     for (int j = 0; j < C; ++j) {
-        float a = wave_sum(tp[j]), b = wave_sum(sp[j]), c = wave_sum(sg[j]);
+        double a = wave_sum_d(tp[j]), b = wave_sum_d(sp[j]), c = wave_sum_d(sg[j]);
         if (lane == 0) { red[wave][j * 3] = a; red[wave][j * 3 + 1] = b; red[wave][j * 3 + 2] = c; }
     }
     __syncthreads();
     if (threadIdx.x < C * 3) {
-        float s = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+        double s = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
         part[((size_t)n * gridDim.x + blockIdx.x) * C * 3 + threadIdx.x] = s;
     }
 }
 
 // one block: stats[n][c][3] and the scalar loss
-__global__ void dice_finalize_kernel(const float* __restrict__ part, float* __restrict__ stats, float* __restrict__ loss,
+__global__ void dice_finalize_kernel(const double* __restrict__ part, float* __restrict__ stats, float* __restrict__ loss,
                                      int N, int C, int nblk, float eps) {
     __shared__ double acc[256];
     double my = 0.0;
     for (int i = threadIdx.x; i < N * C; i += blockDim.x) {
         int n = i / C, c = i - n * C;
         double tp = 0.0, sp = 0.0, sg = 0.0;
-        const float* p = part + ((size_t)n * nblk * C + c) * 3;
+        const double* p = part + ((size_t)n * nblk * C + c) * 3;
         for (int q = 0; q < nblk; ++q) {
-            tp += (double)p[(size_t)q * C * 3];
-            sp += (double)p[(size_t)q * C * 3 + 1];
-            sg += (double)p[(size_t)q * C * 3 + 2];
+            tp += p[(size_t)q * C * 3];
+            sp += p[(size_t)q * C * 3 + 1];
+            sg += p[(size_t)q * C * 3 + 2];
         }
         stats[i * 3] = (float)tp;
         stats[i * 3 + 1] = (float)sp;
@@ -173,7 +173,7 @@ static int dice_check(const Mri3dDiceGeom* g, const char* who) {
 
 extern "C" size_t mri3d_softmax_dice_workspace_bytes(const Mri3dDiceGeom* g) {
     if (!g) return 0;
-    return (size_t)(kDiceMaxBlocks + g->n) * g->c * 3 * sizeof(float);
+    return (size_t)(kDiceMaxBlocks + g->n) * g->c * 3 * sizeof(double);
 }
 
 #define DICE_DISPATCH(CALL)                 \
@@ -196,7 +196,7 @@ extern "C" int mri3d_softmax_dice_fwd(const Mri3dDiceGeom* g, const void* logits
                   "softmax_dice_fwd: workspace %zu < %zu", ws_bytes, mri3d_softmax_dice_workspace_bytes(g));
     hipStream_t s = static_cast<hipStream_t>(stream);
     int nblk = dice_blocks(*g);
-    float* part = static_cast<float*>(workspace);
+    double* part = static_cast<double*>(workspace);
 #define CALL(CC)                                                                                              \
     hipLaunchKernelGGL(dice_fwd_kernel<CC>, dim3(nblk, g->n), dim3(256), 0, s, (const float*)logits,          \
                        (const float*)target, part, g->vox, g->ct, g->x_ld, g->t_ld)

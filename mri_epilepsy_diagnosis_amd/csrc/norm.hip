@@ -52,7 +52,7 @@ static NormPlan norm_plan(const Mri3dNormGeom& g, bool al) {
 size_t norm_workspace_floats(const Mri3dNormGeom& g) {
     // plan with worst-case (vec=1) block count is not needed: nblk <= kMaxStreamBlocks/groups always.
     int groups = g.instance ? g.n : 1;
-    size_t part = (size_t)(kNormMaxBlocks + groups) * g.c * 3;  // per-block partials (groups*nblk <= kNormMaxBlocks, or nblk=1)
+    size_t part = (size_t)(kNormMaxBlocks + groups) * g.c * 3 * 2;  // per-block partials in double (groups*nblk <= kNormMaxBlocks, or nblk=1)
     part += (size_t)groups * g.c * 3;                           // bwd per-(group,channel) sums
     return part;
 }
@@ -80,17 +80,19 @@ struct Ld {
 // partial layout: part[((group*cy... flattened as [group][blk][c][2]
 template <int VEC>
 __global__ void __launch_bounds__(256)
-norm_stats_kernel(const float* __restrict__ x, float* __restrict__ part, int C, int ld, int64_t gvox, int CL, int VT) {
-    __shared__ float red[256 * 2 * VEC];
+norm_stats_kernel(const float* __restrict__ x, double* __restrict__ part, int C, int ld, int64_t gvox, int CL, int VT) {
+    __shared__ double red[256 * 2 * VEC];
     const int tid = threadIdx.x;
     const int cl = tid % CL, vt = tid / CL;
     const int c0 = (blockIdx.y * CL + cl) * VEC;
     const bool active = vt < VT && c0 < C;
     const int group = blockIdx.z;
     const float* xg = x + (int64_t)group * gvox * ld;
-    float s[VEC], ss[VEC], k[VEC];
+    // double accumulators: torch's CPU batch-norm (the oracle's arithmetic) accumulates float sums in double
+    double s[VEC], ss[VEC];
+    float k[VEC];
 #pragma unroll
-    for (int j = 0; j < VEC; ++j) { s[j] = 0.f; ss[j] = 0.f; k[j] = 0.f; }
+    for (int j = 0; j < VEC; ++j) { s[j] = 0.0; ss[j] = 0.0; k[j] = 0.f; }
     if (active) {
         Ld<VEC>::load(xg + c0, k);  // shift = first voxel of the group: removes E[x^2]-E[x]^2 cancellation
         for (int64_t v = (int64_t)blockIdx.x * VT + vt; v < gvox; v += (int64_t)gridDim.x * VT) {
@@ -98,9 +100,9 @@ norm_stats_kernel(const float* __restrict__ x, float* __restrict__ part, int C, 
             Ld<VEC>::load(xg + v * ld + c0, xv);
 #pragma unroll
             for (int j = 0; j < VEC; ++j) {
-                float d = xv[j] - k[j];
+                const double d = (double)(xv[j] - k[j]);
                 s[j] += d;
-                ss[j] = fmaf(d, d, ss[j]);
+                ss[j] = fma(d, d, ss[j]);
             }
         }
     }
@@ -110,12 +112,12 @@ norm_stats_kernel(const float* __restrict__ x, float* __restrict__ part, int C, 
     if (vt == 0 && c0 < C) {
 #pragma unroll
         for (int j = 0; j < VEC; ++j) {
-            float a = 0.f, b = 0.f;
+            double a = 0.0, b = 0.0;
             for (int q = 0; q < VT; ++q) {
                 a += red[((q * CL + cl) * VEC + j) * 2];
                 b += red[((q * CL + cl) * VEC + j) * 2 + 1];
             }
-            float* o = part + (((size_t)group * gridDim.x + blockIdx.x) * C + c0 + j) * 2;
+            double* o = part + (((size_t)group * gridDim.x + blockIdx.x) * C + c0 + j) * 2;
             o[0] = a;
             o[1] = b;
         }
@@ -123,7 +125,7 @@ norm_stats_kernel(const float* __restrict__ x, float* __restrict__ part, int C, 
 }
 
 __global__ void __launch_bounds__(256)
-norm_stats_finalize_kernel(const float* __restrict__ x, const float* __restrict__ part,
+norm_stats_finalize_kernel(const float* __restrict__ x, const double* __restrict__ part,
                            float* __restrict__ mean, float* __restrict__ invstd,
                            float* __restrict__ running_mean, float* __restrict__ running_var,
                            float momentum, float eps, int C, int ld, int64_t gvox, int nblk, int groups) {
@@ -135,10 +137,10 @@ norm_stats_finalize_kernel(const float* __restrict__ x, const float* __restrict_
     const int group = ok ? i / C : 0, c = ok ? i - group * C : 0;
     double a = 0.0, b = 0.0;
     if (ok) {
-        const float* p = part + ((size_t)group * nblk * C + c) * 2;
+        const double* p = part + ((size_t)group * nblk * C + c) * 2;
         for (int q = ql; q < nblk; q += kFinQL) {
-            a += (double)p[(size_t)q * C * 2];
-            b += (double)p[(size_t)q * C * 2 + 1];
+            a += p[(size_t)q * C * 2];
+            b += p[(size_t)q * C * 2 + 1];
         }
     }
     ra[threadIdx.x] = a;
@@ -205,20 +207,20 @@ norm_act_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, const fl
 // part[group][blk][c][3] = (sum du, sum du*xhat, sum dy*u*[u<=0])
 template <int VEC>
 __global__ void __launch_bounds__(256)
-norm_act_bwd_reduce_kernel(const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ part,
+norm_act_bwd_reduce_kernel(const float* __restrict__ x, const float* __restrict__ dy, double* __restrict__ part,
                            const float* __restrict__ mean, const float* __restrict__ invstd,
                            const float* __restrict__ gamma, const float* __restrict__ beta,
                            const float* __restrict__ alpha, int alpha_n, int act, float slope, int C, int x_ld,
                            int y_ld, int64_t gvox, int CL, int VT) {
-    __shared__ float red[256 * 3 * VEC];
+    __shared__ double red[256 * 3 * VEC];
     const int tid = threadIdx.x;
     const int cl = tid % CL, vt = tid / CL;
     const int c0 = (blockIdx.y * CL + cl) * VEC;
     const bool active = vt < VT && c0 < C;
     const int group = blockIdx.z;
-    float s0[VEC], s1[VEC], s2[VEC];
+    double s0[VEC], s1[VEC], s2[VEC];
 #pragma unroll
-    for (int j = 0; j < VEC; ++j) { s0[j] = 0.f; s1[j] = 0.f; s2[j] = 0.f; }
+    for (int j = 0; j < VEC; ++j) { s0[j] = 0.0; s1[j] = 0.0; s2[j] = 0.0; }
     if (active) {
         float mu[VEC], is[VEC], gm[VEC], bt[VEC], al[VEC];
 #pragma unroll
@@ -243,9 +245,9 @@ norm_act_bwd_reduce_kernel(const float* __restrict__ x, const float* __restrict_
                 float u = fmaf(gm[j], xh, bt[j]);
                 bool pos = u > 0.f;
                 float du = pos ? gv[j] : gv[j] * al[j];
-                s0[j] += du;
-                s1[j] = fmaf(du, xh, s1[j]);
-                s2[j] += pos ? 0.f : gv[j] * u;
+                s0[j] += (double)du;
+                s1[j] = fma((double)du, (double)xh, s1[j]);
+                s2[j] += pos ? 0.0 : (double)gv[j] * (double)u;
             }
         }
     }
@@ -259,13 +261,13 @@ norm_act_bwd_reduce_kernel(const float* __restrict__ x, const float* __restrict_
     if (vt == 0 && c0 < C) {
 #pragma unroll
         for (int j = 0; j < VEC; ++j) {
-            float a = 0.f, b = 0.f, d = 0.f;
+            double a = 0.0, b = 0.0, d = 0.0;
             for (int q = 0; q < VT; ++q) {
                 a += red[((q * CL + cl) * VEC + j) * 3];
                 b += red[((q * CL + cl) * VEC + j) * 3 + 1];
                 d += red[((q * CL + cl) * VEC + j) * 3 + 2];
             }
-            float* o = part + (((size_t)group * gridDim.x + blockIdx.x) * C + c0 + j) * 3;
+            double* o = part + (((size_t)group * gridDim.x + blockIdx.x) * C + c0 + j) * 3;
             o[0] = a;
             o[1] = b;
             o[2] = d;
@@ -275,7 +277,7 @@ norm_act_bwd_reduce_kernel(const float* __restrict__ x, const float* __restrict_
 
 // Stage A: sums[group][c][3] = fixed-order double sums of the per-block partials.
 __global__ void __launch_bounds__(256)
-norm_act_bwd_sums_kernel(const float* __restrict__ part, float* __restrict__ sums, int C, int nblk, int groups) {
+norm_act_bwd_sums_kernel(const double* __restrict__ part, float* __restrict__ sums, int C, int nblk, int groups) {
     __shared__ double r0[256], r1[256], r2[256];
     const int slot = threadIdx.x / kFinQL, ql = threadIdx.x % kFinQL;
     const int i = blockIdx.x * (256 / kFinQL) + slot;
@@ -283,11 +285,11 @@ norm_act_bwd_sums_kernel(const float* __restrict__ part, float* __restrict__ sum
     const int group = ok ? i / C : 0, c = ok ? i - group * C : 0;
     double a = 0.0, b = 0.0, d = 0.0;
     if (ok) {
-        const float* p = part + ((size_t)group * nblk * C + c) * 3;
+        const double* p = part + ((size_t)group * nblk * C + c) * 3;
         for (int q = ql; q < nblk; q += kFinQL) {
-            a += (double)p[(size_t)q * C * 3];
-            b += (double)p[(size_t)q * C * 3 + 1];
-            d += (double)p[(size_t)q * C * 3 + 2];
+            a += p[(size_t)q * C * 3];
+            b += p[(size_t)q * C * 3 + 1];
+            d += p[(size_t)q * C * 3 + 2];
         }
     }
     r0[threadIdx.x] = a;
@@ -419,7 +421,7 @@ extern "C" int mri3d_norm_stats(const Mri3dNormGeom* g, const void* x, float* me
     Mri3dNormGeom gg = *g;
     gg.y_ld = gg.x_ld;
     NormPlan p = norm_plan(gg, aligned16(x));
-    float* part = static_cast<float*>(workspace);
+    double* part = static_cast<double*>(workspace);
     const float* xf = static_cast<const float*>(x);
     dim3 grid(p.nblk, p.cy, p.groups);
     if (p.vec == 4)
@@ -473,8 +475,8 @@ extern "C" int mri3d_norm_act_bwd(const Mri3dNormGeom* g, int training, const vo
     const float* xf = static_cast<const float*>(x);
     const float* df = static_cast<const float*>(dy);
     float* of = static_cast<float*>(dx);
-    float* part = static_cast<float*>(workspace);
-    float* sums = part + (size_t)p.groups * p.nblk * g->c * 3;
+    double* part = static_cast<double*>(workspace);
+    float* sums = reinterpret_cast<float*>(part + (size_t)p.groups * p.nblk * g->c * 3);
     const bool need_reduce = training || dgamma || dbeta || dalpha;
     if (need_reduce) {
         if (p.vec == 4)

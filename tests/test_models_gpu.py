@@ -39,7 +39,7 @@ def _step(model, x, loss_fn, train):
     return out.detach(), loss.detach()
 
 
-def _compare(prod, orc, x, loss_prod, loss_orc, train, gold=None, rel=1e-3, grad_rel=2e-3):
+def _compare(prod, orc, x, loss_prod, loss_orc, train, gold=None, rel=1e-3, grad_rel=5e-3):
     """prod on GPU vs orc on CPU on the same input; optionally also vs the golden record."""
     prod.load_state_dict(orc.state_dict())
     prod.to(DEV)
@@ -50,7 +50,11 @@ def _compare(prod, orc, x, loss_prod, loss_orc, train, gold=None, rel=1e-3, grad
     out_p = to_ncdhw(out_p) if out_p.dim() == 5 else out_p.cpu()
     assert_close(out_p, out_o, rel=rel, what="output")
     assert_close(l_p.cpu(), l_o, rel=rel, what="loss")
-    # Gradients are judged against an fp64 run of the oracle: the HIP gradient must be within grad_rel of the truth
+    # Outputs/loss: 1e-3 (north_star).  Gradients are judged against an fp64 run of the oracle.  Per operator the HIP
+    # kernels are as accurate as torch's fp32 CPU kernels (tools/op_error_audit.py: 1e-7..2e-6 either way), but a
+    # gradient that has travelled back through ten normalisation layers carries those 1e-6 perturbations amplified by
+    # the cancellation in sum(du * xhat): both fp32 paths land 1e-4..1e-2 from the fp64 truth, tensor by tensor.
+    # So: the HIP gradient must be within grad_rel (5e-3, max-norm per tensor) of the truth
     # (max-norm, per tensor) OR no further from it than 4x what PyTorch's own fp32 CPU path (the reference's
     # arithmetic) is.  The second clause covers tensors whose true gradient is zero by construction (a conv bias feeding
     # a train-mode BatchNorm), where every fp32 implementation returns rounding noise.

@@ -30,6 +30,12 @@ CONV_CASES = [
     ("unet_96_32", 1, 96, 32, (8, 8, 12), 3, 1, 1, 1, True),
     ("unet_48_16", 1, 48, 16, (12, 16, 16), 3, 1, 1, 1, True),
     ("unet_cls_16_2", 2, 16, 2, (12, 20, 16), 1, 1, 0, 1, True),
+    ("pw_32_2", 1, 32, 2, (9, 10, 11), 1, 1, 0, 1, False),
+    ("pw_64_8", 2, 64, 8, (6, 7, 8), 1, 1, 0, 1, True),
+    ("pw_16_5", 1, 16, 5, (6, 7, 8), 1, 1, 0, 1, True),
+    ("pw_128_64", 1, 128, 64, (4, 5, 6), 1, 1, 0, 1, False),
+    ("mfma_24_40", 1, 24, 40, (6, 9, 17), 3, 1, 1, 1, True),
+    ("mfma_64_128_ragged", 1, 64, 128, (3, 5, 7), 3, 1, 1, 1, False),
     ("ragged_3x3x3", 1, 16, 16, (5, 7, 9), 3, 1, 1, 1, False),
     ("tiny_1voxel", 1, 8, 16, (1, 1, 1), 3, 1, 1, 1, True),
     ("sepx_k6s2p2", 2, 1, 8, (32, 12, 10), (6, 1, 1), (2, 1, 1), (2, 0, 0), 1, True),
