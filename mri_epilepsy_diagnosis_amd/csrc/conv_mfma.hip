@@ -19,6 +19,7 @@
 // Roofline: compute-bound for Cin*Cout >= 8*16 (AI 72..270 FLOP/B vs ridge ~20): the bound is the fp32
 // MFMA peak; algorithmic FLOPs = 2 * N*D*H*W * Cin * Cout * 27 per pass.
 #include "common.h"
+#include <stdlib.h>
 
 namespace mri3d {
 
@@ -77,7 +78,7 @@ template <int NT, int CK>
 __global__ void __launch_bounds__(256, 2)
 conv_mfma_fwd_kernel(const float* __restrict__ x, const float* __restrict__ wp, const float* __restrict__ bias,
                      float* __restrict__ y, int N, int D, int H, int W, int Kc, int x_ld, int Nc, int y_ld, int NTT,
-                     int tilesD, int tilesH, int tilesW, int ntiles) {
+                     int tilesD, int tilesH, int tilesW, int ntiles, int ablate) {
     constexpr int CP = CK;  // LDS voxel pitch in floats
     constexpr int TG = tap_groups(CK);
     constexpr int Q = CK / 4;
@@ -106,6 +107,7 @@ conv_mfma_fwd_kernel(const float* __restrict__ x, const float* __restrict__ wp, 
     const float* xn = x + (int64_t)n * D * H * W * x_ld;
     for (int ch = 0; ch < nchunks; ++ch) {
         __syncthreads();
+        if (!(ablate & 1))
         for (int idx = tid; idx < HVOX * Q; idx += 256) {
             const int q = idx % Q, v = idx / Q;
             const int wx = v % HW;
@@ -119,38 +121,63 @@ conv_mfma_fwd_kernel(const float* __restrict__ x, const float* __restrict__ wp, 
         }
         __syncthreads();
 
+        // Software pipeline over the tap groups: B fragments (global, L1/L2-resident packed weights) are fetched two
+        // tap groups ahead into a 3-deep register ring, A fragments (LDS) one tap group ahead into a 2-deep ring, so
+        // neither latency sits in front of an MFMA.
+        if (ablate & 2) continue;
         const float* wt = wp + ((size_t)ch * TG * NTT + nt0) * 256 + lane * 4;
-#pragma unroll
-        for (int tg = 0; tg < TG; ++tg, wt += NTT * 256) {
-            f32x4 bfrag[NT];
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt) bfrag[nt] = *reinterpret_cast<const f32x4*>(wt + nt * 256);
-            int aoff;
+        const size_t wstep = (size_t)NTT * 256;
+        f32x4 bq[3][NT];
+        f32x4 aq[2][TH];
+        auto a_off = [&](int tg) -> int {
             if (CK == 16) {
                 const int kd = tg / 9, kh = (tg / 3) % 3, kw = tg % 3;
-                aoff = (((wv + kd) * HH + kh) * HW + (li + kw)) * CP + 4 * kq;
+                return (((wv + kd) * HH + kh) * HW + (li + kw)) * CP + 4 * kq;
             } else {
                 const int ta = 2 * tg, tb = (2 * tg + 1 < 27) ? 2 * tg + 1 : 26;  // tap 27 has zero weights
                 const int oa = ((ta / 9) * HH + (ta / 3) % 3) * HW + ta % 3;
                 const int ob = ((tb / 9) * HH + (tb / 3) % 3) * HW + tb % 3;
-                aoff = ((wv * HH) * HW + li + ((kq >> 1) ? ob : oa)) * CP + 4 * (kq & 1);
+                return ((wv * HH) * HW + li + ((kq >> 1) ? ob : oa)) * CP + 4 * (kq & 1);
             }
-            f32x4 a[TH];
+        };
 #pragma unroll
-            for (int m = 0; m < TH; ++m) a[m] = *reinterpret_cast<const f32x4*>(lds + aoff + m * HW * CP);
+        for (int nt = 0; nt < NT; ++nt) {
+            bq[0][nt] = *reinterpret_cast<const f32x4*>(wt + nt * 256);
+            bq[1][nt] = *reinterpret_cast<const f32x4*>(wt + wstep + nt * 256);
+        }
+        {
+            const int o0 = a_off(0);
+#pragma unroll
+            for (int m = 0; m < TH; ++m) aq[0][m] = *reinterpret_cast<const f32x4*>(lds + o0 + m * HW * CP);
+        }
+#pragma unroll
+        for (int tg = 0; tg < TG; ++tg) {
+            const int cur = tg % 3, nxt2 = (tg + 2) % 3, ac = tg & 1, an = (tg + 1) & 1;
+            if (tg + 2 < TG) {
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+                    bq[nxt2][nt] = *reinterpret_cast<const f32x4*>(wt + (size_t)(tg + 2) * wstep + nt * 256);
+            }
+            if (tg + 1 < TG) {
+                const int o1 = a_off(tg + 1);
+#pragma unroll
+                for (int m = 0; m < TH; ++m) aq[an][m] = *reinterpret_cast<const f32x4*>(lds + o1 + m * HW * CP);
+            }
+            // keep the prefetches ABOVE this tap group's MFMAs (hipcc otherwise sinks them next to their first use)
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int s = 0; s < 4; ++s)
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
                     for (int m = 0; m < TH; ++m)
-                        acc[m][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[m][s], bfrag[nt][s], acc[m][nt], 0, 0, 0);
+                        acc[m][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(aq[ac][m][s], bq[cur][nt][s], acc[m][nt], 0, 0, 0);
         }
     }
 
     // epilogue: lane holds rows (voxels) 4*kq + r, column (channel) li of every 16x16 tile
     const int od = d0 + wv;
-    if (od < D) {
+    if (od < D && !(ablate & 4)) {
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
             const int co = (nt0 + nt) * 16 + li;
@@ -171,9 +198,207 @@ conv_mfma_fwd_kernel(const float* __restrict__ x, const float* __restrict__ wp, 
     }
 }
 
+// ------------------------------------------------------------------ forward / dgrad kernel, version 2
+// Persistent workgroups + double-buffered LDS + staging folded into the tap loop.
+//   v1 (above) alternates "stage a chunk" and "27 tap groups of MFMA" with a barrier pair in between; the two
+//   workgroups resident on a CU run in lock-step, so the staging time (1.0 of 4.1 ms on the 48->16 layer, measured by
+//   ablation) is NOT hidden.  v2 makes each workgroup self-overlapping:
+//     * K is consumed in 8-channel chunks (two taps share an MFMA k-step: 14 tap groups per chunk), so TWO halo tiles
+//       fit in LDS (2 x 34.5 KB) with two workgroups per CU;
+//     * while chunk i is multiplied out of buffer i&1, every lane also fetches its 9 16-byte pieces of chunk i+1 (of the
+//       same tile or the next one of this workgroup's range) — one global load per tap group, written to buffer
+//       (i+1)&1 three tap groups later — so global latency, LDS writes and MFMAs overlap; one barrier per chunk;
+//     * operands are passed to the MFMA as (weights, voxels): the accumulator then holds 4 consecutive output channels
+//       of one voxel per lane and the epilogue is a fully coalesced 16-byte store per lane (1 KiB per wave).
+constexpr int kStg = (HVOX * 2 + 255) / 256;  // 16-byte staging pieces per lane per 8-channel chunk (9)
+
+template <int NT>
+__global__ void __launch_bounds__(256, 2)
+conv_mfma_fwd2_kernel(const float* __restrict__ x, const float* __restrict__ wp, const float* __restrict__ bias,
+                      float* __restrict__ y, int N, int D, int H, int W, int Kc, int x_ld, int Nc, int y_ld, int NTT,
+                      int gy, int tilesD, int tilesH, int tilesW, int ntiles) {
+    constexpr int CK = 8, CP = 8, TG = 14;
+    constexpr int BUF = kStg * 256 * 4;  // floats per LDS buffer: the halo tile rounded up to kStg 16-byte pieces per lane
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int li = lane & 15, kq = lane >> 4;
+    const int nchunks = Kc / CK;
+    const int t_lo = (int)(((int64_t)ntiles * blockIdx.x) / gridDim.x);
+    const int t_hi = (int)(((int64_t)ntiles * (blockIdx.x + 1)) / gridDim.x);
+    const int nitems = (t_hi - t_lo) * nchunks;
+    if (nitems <= 0) return;
+
+    // per-lane staging geometry (independent of the item): piece j covers halo voxel (j*256+tid)>>1, channel quad &1
+    // (pieces past the tile's end alias voxel 0 and land in the buffer's padding: no lane ever branches)
+    int srel[kStg];  // packed (dz, hy, wx)
+#pragma unroll
+    for (int j = 0; j < kStg; ++j) {
+        const int idx = j * 256 + tid;
+        const int v = idx < HVOX * 2 ? idx >> 1 : 0;
+        const int wx = v % HW, t2 = v / HW;
+        srel[j] = ((t2 / HH) << 16) | ((t2 % HH) << 8) | wx;
+    }
+
+    struct Item { int n, d0, h0, w0, nt0, ch; };
+    auto decode = [&](int it) -> Item {
+        Item r;
+        int tile = t_lo + it / nchunks;
+        r.ch = it % nchunks;
+        r.nt0 = (tile % gy) * NT;
+        tile /= gy;
+        r.w0 = (tile % tilesW) * TW;
+        tile /= tilesW;
+        r.h0 = (tile % tilesH) * TH;
+        tile /= tilesH;
+        r.d0 = (tile % tilesD) * TD;
+        r.n = tile / tilesD;
+        return r;
+    };
+    // The load is UNCONDITIONAL (clamped address); out-of-volume pieces are zeroed only when they are written to LDS
+    // three tap groups later.  A load inside a branch makes hipcc treat it as "maybe not issued" and shorten every
+    // later vmcnt wait of the B ring to cover it (12 % measured); zeroing right after the load forces vmcnt(0).
+    unsigned okmask = 0;
+    auto stage_load = [&](const Item& it, int j) -> float4 {
+        const int r = srel[j];
+        const int gd = it.d0 - 1 + (r >> 16), gh = it.h0 - 1 + ((r >> 8) & 0xff), gw = it.w0 - 1 + (r & 0xff);
+        const bool ok = (unsigned)gd < (unsigned)D && (unsigned)gh < (unsigned)H && (unsigned)gw < (unsigned)W;
+        okmask = ok ? (okmask | (1u << j)) : (okmask & ~(1u << j));
+        const int cd = min(max(gd, 0), D - 1), chh = min(max(gh, 0), H - 1), cw = min(max(gw, 0), W - 1);
+        return *reinterpret_cast<const float4*>(x + ((((int64_t)it.n * D + cd) * H + chh) * W + cw) * x_ld + it.ch * CK +
+                                                4 * (tid & 1));
+    };
+    auto stage_store = [&](float* buf, int j, const float4& val) {
+        const bool ok = (okmask >> j) & 1u;
+        float4 v2;
+        v2.x = ok ? val.x : 0.f;
+        v2.y = ok ? val.y : 0.f;
+        v2.z = ok ? val.z : 0.f;
+        v2.w = ok ? val.w : 0.f;
+        *reinterpret_cast<float4*>(buf + (j * 256 + tid) * 4) = v2;
+    };
+
+    // prologue: item 0 -> buffer 0
+    Item cur = decode(0);
+    {
+        float4 tmp[kStg];
+#pragma unroll
+        for (int j = 0; j < kStg; ++j) tmp[j] = stage_load(cur, j);
+#pragma unroll
+        for (int j = 0; j < kStg; ++j) stage_store(lds, j, tmp[j]);
+    }
+    __syncthreads();
+
+    f32x4 acc[TH][NT];
+#pragma unroll
+    for (int m = 0; m < TH; ++m)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc[m][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // A-fragment LDS offsets of a tap group (k-groups 0,1 = tap 2t; k-groups 2,3 = tap 2t+1, tap 27 = zero weights)
+    auto a_off = [&](int tg) -> int {
+        const int ta = 2 * tg, tb = (2 * tg + 1 < 27) ? 2 * tg + 1 : 26;
+        const int oa = ((ta / 9) * HH + (ta / 3) % 3) * HW + ta % 3;
+        const int ob = ((tb / 9) * HH + (tb / 3) % 3) * HW + tb % 3;
+        return ((wv * HH) * HW + li + ((kq >> 1) ? ob : oa)) * CP + 4 * (kq & 1);
+    };
+
+    for (int it = 0; it < nitems; ++it) {
+        const float* bufc = lds + (it & 1) * BUF;
+        float* bufn = lds + ((it + 1) & 1) * BUF;
+        const bool has_next = it + 1 < nitems;
+        Item nxt = cur;
+        if (has_next) nxt = decode(it + 1);
+
+        const float* wt = wp + ((size_t)cur.ch * TG * NTT + cur.nt0) * 256 + lane * 4;
+        const size_t wstep = (size_t)NTT * 256;
+        f32x4 bq[3][NT];
+        f32x4 aq[2][TH];
+        float4 sq[4];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            bq[0][nt] = *reinterpret_cast<const f32x4*>(wt + nt * 256);
+            bq[1][nt] = *reinterpret_cast<const f32x4*>(wt + wstep + nt * 256);
+        }
+        {
+            const int o0 = a_off(0);
+#pragma unroll
+            for (int m = 0; m < TH; ++m) aq[0][m] = *reinterpret_cast<const f32x4*>(bufc + o0 + m * HW * CP);
+        }
+#pragma unroll
+        for (int tg = 0; tg < TG; ++tg) {
+            const int cb = tg % 3, nb = (tg + 2) % 3, ac = tg & 1, an = (tg + 1) & 1;
+            if (tg < kStg) sq[tg & 3] = stage_load(nxt, tg);  // next chunk: global -> regs (unconditional)
+            if (tg + 2 < TG) {
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+                    bq[nb][nt] = *reinterpret_cast<const f32x4*>(wt + (size_t)(tg + 2) * wstep + nt * 256);
+            }
+            if (tg >= 3 && tg - 3 < kStg) stage_store(bufn, tg - 3, sq[(tg - 3) & 3]);  // regs -> LDS
+            if (tg + 1 < TG) {
+                const int o1 = a_off(tg + 1);
+#pragma unroll
+                for (int m = 0; m < TH; ++m) aq[an][m] = *reinterpret_cast<const f32x4*>(bufc + o1 + m * HW * CP);
+            }
+            __builtin_amdgcn_sched_barrier(0);  // keep the prefetches above this tap group's MFMAs
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                    for (int m = 0; m < TH; ++m)
+                        acc[m][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(bq[cb][nt][s], aq[ac][m][s], acc[m][nt], 0, 0, 0);
+        }
+
+        if (cur.ch == nchunks - 1) {
+            // epilogue: lane holds channels 4*kq..4*kq+3 of voxel li of every 16x16 tile
+            const int od = cur.d0 + wv;
+            if (od < D) {
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                    const int co = (cur.nt0 + nt) * 16 + 4 * kq;
+                    if (co < Nc) {
+                        const bool vec = (co + 3 < Nc) && ((y_ld & 3) == 0);
+                        float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+                        if (bias) {
+                            bv.x = bias[co];
+                            if (co + 1 < Nc) bv.y = bias[co + 1];
+                            if (co + 2 < Nc) bv.z = bias[co + 2];
+                            if (co + 3 < Nc) bv.w = bias[co + 3];
+                        }
+                        const int ow = cur.w0 + li;
+#pragma unroll
+                        for (int m = 0; m < TH; ++m) {
+                            const int oh = cur.h0 + m;
+                            if (oh < H && ow < W) {
+                                float* yp = y + ((((int64_t)cur.n * D + od) * H + oh) * W + ow) * y_ld + co;
+                                const f32x4 a = acc[m][nt];
+                                if (vec) {
+                                    *reinterpret_cast<float4*>(yp) = make_float4(a[0] + bv.x, a[1] + bv.y, a[2] + bv.z, a[3] + bv.w);
+                                } else {
+                                    yp[0] = a[0] + bv.x;
+                                    if (co + 1 < Nc) yp[1] = a[1] + bv.y;
+                                    if (co + 2 < Nc) yp[2] = a[2] + bv.z;
+                                    if (co + 3 < Nc) yp[3] = a[3] + bv.w;
+                                }
+                            }
+                        }
+                    }
+                }
+            }
+#pragma unroll
+            for (int m = 0; m < TH; ++m)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) acc[m][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        __syncthreads();  // buffer (it+1)&1 is complete; buffer it&1 may be overwritten from the next iteration on
+        cur = nxt;
+    }
+}
+
 // ------------------------------------------------------------------ host side
 struct MfmaFwdPlan {
-    int CK, NT, NTT, gy, nchunks, tilesD, tilesH, tilesW, ntiles;
+    int CK, NT, NTT, gy, nchunks, tilesD, tilesH, tilesW, ntiles, v2, grid;
     size_t wp_floats, smem;
 };
 
@@ -185,13 +410,15 @@ static bool mfma_fwd_plan(const Mri3dConvGeom& g, bool dgrad, MfmaFwdPlan& p) {
     const int in_ld = dgrad ? g.y_ld : g.x_ld;
     if (Kc % 8 != 0 || in_ld % 4 != 0) return false;
     if (Nc < 8) return false;  // tiny outputs (e.g. 16->2) stay on the direct kernel
-    p.CK = (Kc % 16 == 0) ? 16 : 8;
+    static const int use_v1 = getenv("MRI3D_FWD_V1") ? atoi(getenv("MRI3D_FWD_V1")) : 0;  // tuning aid (A/B)
+    p.v2 = use_v1 ? 0 : 1;
+    p.CK = (Kc % 16 == 0 && !p.v2) ? 16 : 8;
     p.NTT = cdiv(Nc, 16);
-    if (p.NTT % 4 == 0) p.NT = 4;
-    else if (p.NTT % 3 == 0) p.NT = 3;
+    // NT (16-channel N-tiles per wave) is capped by registers: v1 holds 8*NT accumulators + 2-deep A / 3-deep B rings
+    // (NT <= 3); v2 adds the staging ring (NT <= 2).  Wider outputs are split over gy passes of the same tile.
+    if (p.NTT % 3 == 0 && !p.v2) p.NT = 3;
     else if (p.NTT % 2 == 0) p.NT = 2;
     else p.NT = 1;
-    if (p.NTT > 4 && p.NT == 1) return false;  // odd large tile counts: not needed by any model here
     p.gy = p.NTT / p.NT;
     p.nchunks = Kc / p.CK;
     p.tilesD = cdiv(g.di, TD);
@@ -201,7 +428,12 @@ static bool mfma_fwd_plan(const Mri3dConvGeom& g, bool dgrad, MfmaFwdPlan& p) {
     if (nt > 0x7fffffff) return false;
     p.ntiles = (int)nt;
     p.wp_floats = (size_t)p.nchunks * tap_groups(p.CK) * p.NTT * 256;
-    p.smem = (size_t)HVOX * p.CK * sizeof(float);
+    p.smem = p.v2 ? (size_t)2 * kStg * 256 * 16 : (size_t)HVOX * p.CK * sizeof(float);
+    if (p.v2) {
+        int64_t st = (int64_t)p.ntiles * p.gy;  // (spatial tile, n-tile block) work units
+        if (st > 0x7fffffff) return false;
+        p.grid = (int)std::min<int64_t>(st, 512);  // 2 resident workgroups per CU x 256 CUs
+    }
     return true;
 }
 
@@ -212,8 +444,9 @@ static void launch_mfma_fwd(const MfmaFwdPlan& p, const float* in, const float* 
     if (p.smem > 64 * 1024)
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                   (int)p.smem);
+    static const int ablate = getenv("MRI3D_ABLATE") ? atoi(getenv("MRI3D_ABLATE")) : 0;  // tuning aid: 1 = skip staging, 2 = skip MFMA loop, 4 = skip stores
     hipLaunchKernelGGL(kern, dim3(p.ntiles, p.gy), dim3(256), p.smem, s, in, wp, bias, out, N, D, H, W, Kc, in_ld, Nc,
-                       out_ld, p.NTT, p.tilesD, p.tilesH, p.tilesW, p.ntiles);
+                       out_ld, p.NTT, p.tilesD, p.tilesH, p.tilesW, p.ntiles, ablate);
 }
 
 static int run_mfma_fwd(const Mri3dConvGeom& g, bool dgrad, const float* in, const float* w, const float* bias,
@@ -230,17 +463,31 @@ static int run_mfma_fwd(const Mri3dConvGeom& g, bool dgrad, const float* in, con
     int total = (int)p.wp_floats;
     hipLaunchKernelGGL(pack_w_mfma_kernel, dim3(std::min(cdiv(total, 256), 2048)), dim3(256), 0, s, w, wp, g.co, g.ci,
                        dgrad ? 1 : 0, p.CK, p.NTT, p.nchunks);
+    if (p.v2) {
+        const int st = p.ntiles * p.gy;
+        const size_t smem = p.smem;
+#define MRI3D_FWD2_CASE(NTv)                                                                                          \
+    if (p.NT == NTv) {                                                                                                \
+        auto kern = conv_mfma_fwd2_kernel<NTv>;                                                                       \
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,   \
+                                  (int)smem);                                                                         \
+        hipLaunchKernelGGL(kern, dim3(p.grid), dim3(256), smem, s, in, wp, bias, out, g.n, g.di, g.hi, g.wi, Kc,      \
+                           in_ld, Nc, out_ld, p.NTT, p.gy, p.tilesD, p.tilesH, p.tilesW, st);                                \
+    }
+        MRI3D_FWD2_CASE(1)
+        MRI3D_FWD2_CASE(2)
+#undef MRI3D_FWD2_CASE
+        return check_launch(dgrad ? "conv3d_dgrad(mfma2)" : "conv3d_fwd(mfma2)");
+    }
 #define MRI3D_FWD_CASE(NTv, CKv)                                                                                      \
     if (p.NT == NTv && p.CK == CKv)                                                                                   \
         launch_mfma_fwd<NTv, CKv>(p, in, wp, bias, out, g.n, g.di, g.hi, g.wi, Kc, in_ld, Nc, out_ld, s);
     MRI3D_FWD_CASE(1, 16)
     MRI3D_FWD_CASE(2, 16)
     MRI3D_FWD_CASE(3, 16)
-    MRI3D_FWD_CASE(4, 16)
     MRI3D_FWD_CASE(1, 8)
     MRI3D_FWD_CASE(2, 8)
     MRI3D_FWD_CASE(3, 8)
-    MRI3D_FWD_CASE(4, 8)
 #undef MRI3D_FWD_CASE
     return check_launch(dgrad ? "conv3d_dgrad(mfma)" : "conv3d_fwd(mfma)");
 }
