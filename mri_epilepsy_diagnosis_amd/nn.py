@@ -41,13 +41,15 @@ def _act_spec(act):
     raise NotImplementedError("unsupported activation module %r" % (act,))
 
 
-def fused_norm_act(norm, act, x):
-    """act(norm(x)) in one pass.  `norm` is a BatchNorm3d / InstanceNorm3d module or None; `act` an activation or None."""
+def fused_norm_act(norm, act, x, out=None):
+    """act(norm(x)) in one pass.  `norm` is a BatchNorm3d / InstanceNorm3d module or None; `act` an activation or None.
+    `out=(buffer, channel_offset)` makes the kernel write straight into a channel slice of a wider NDHWC buffer (a
+    decoder concat buffer) and returns that slice as a view."""
     kind, alpha, slope = _act_spec(act)
     if norm is None:
-        if kind is None:
+        if kind is None and out is None:
             return x
-        return ops.activation(x, kind, alpha, slope)
+        return ops.norm_act(x, None, None, alpha, None, None, "none", 0.1, 0.0, kind, slope, out)
     if isinstance(norm, tnn.modules.batchnorm._BatchNorm):
         use_batch = norm.training or norm.running_mean is None
         if norm.training and norm.track_running_stats and norm.num_batches_tracked is not None:
@@ -56,11 +58,11 @@ def fused_norm_act(norm, act, x):
                             norm.running_mean if norm.track_running_stats else None,
                             norm.running_var if norm.track_running_stats else None,
                             "batch" if use_batch else "running",
-                            norm.momentum, norm.eps, kind, slope)
+                            norm.momentum, norm.eps, kind, slope, out)
     if isinstance(norm, tnn.modules.instancenorm._InstanceNorm):
         if norm.track_running_stats:
             raise NotImplementedError("InstanceNorm3d(track_running_stats=True) is not supported")
-        return ops.norm_act(x, norm.weight, norm.bias, alpha, None, None, "instance", 0.1, norm.eps, kind, slope)
+        return ops.norm_act(x, norm.weight, norm.bias, alpha, None, None, "instance", 0.1, norm.eps, kind, slope, out)
     raise NotImplementedError("unsupported normalisation module %r" % (norm,))
 
 

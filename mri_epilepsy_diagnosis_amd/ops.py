@@ -57,6 +57,43 @@ def _cl(x):
     return x.contiguous(memory_format=CL3D)
 
 
+def _pitch_of(x):
+    """Voxel pitch ld if x's memory is NDHWC with pitch ld >= C (dense, or a channel slice of a wider NDHWC buffer),
+    else None."""
+    n, c, d, h, w = x.shape
+    if c > 1 and x.stride(1) != 1:
+        return None
+    ld = None
+    for size, stride, inner in ((w, x.stride(4), 1), (h, x.stride(3), w), (d, x.stride(2), h * w), (n, x.stride(0), d * h * w)):
+        if size > 1:
+            if stride % inner:
+                return None
+            cand = stride // inner
+            if ld is None:
+                ld = cand
+            elif cand != ld:
+                return None
+    if ld is None:
+        ld = c
+    return ld if ld >= c else None
+
+
+def _nd(x):
+    """(tensor, ld): x itself when it is NDHWC with some voxel pitch (no copy), else a dense NDHWC copy."""
+    if x.dim() != 5:
+        raise RuntimeError("expected a 5-D (N,C,D,H,W) tensor, got shape %s" % (tuple(x.shape),))
+    ld = _pitch_of(x)
+    if ld is not None:
+        return x, ld
+    x = x.contiguous(memory_format=CL3D)
+    return x, x.shape[1]
+
+
+def _slice_view(buf, off, c):
+    """Channel slice [off, off+c) of an NDHWC buffer as a logical (N, c, D, H, W) tensor (pitched view, no copy)."""
+    return buf.narrow(1, off, c)
+
+
 def _new(shape, like):
     return torch.empty(shape, dtype=like.dtype, device=like.device, memory_format=CL3D)
 
@@ -152,7 +189,7 @@ def _triple(v):
 # ----------------------------------------------------------------------------------------------- conv
 
 
-def _conv_geom(xshape, wshape, stride, padding, dilation):
+def _conv_geom(xshape, wshape, stride, padding, dilation, x_ld=None, y_ld=None):
     n, ci, di, hi, wi = xshape
     co, ci_w, kd, kh, kw = wshape
     if ci_w != ci:
@@ -165,7 +202,8 @@ def _conv_geom(xshape, wshape, stride, padding, dilation):
     wo = (wi + 2 * pw - dw * (kw - 1) - 1) // sw + 1
     if do <= 0 or ho <= 0 or wo <= 0:
         raise RuntimeError("Kernel size can't be greater than actual input size")
-    return ConvGeom(n, di, hi, wi, ci, do, ho, wo, co, kd, kh, kw, sd, sh, sw, pd, ph, pw, dd, dh, dw, ci, co, F32)
+    return ConvGeom(n, di, hi, wi, ci, do, ho, wo, co, kd, kh, kw, sd, sh, sw, pd, ph, pw, dd, dh, dw,
+                    ci if x_ld is None else x_ld, co if y_ld is None else y_ld, F32)
 
 
 def _conv_fwd(g, x, w, b):
@@ -206,9 +244,9 @@ class _Conv3dFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias, stride, padding, dilation):
         _require_device(x, weight, bias)
-        x = _cl(x)
+        x, x_ld = _nd(x)
         w = weight.contiguous()
-        g = _conv_geom(x.shape, w.shape, stride, padding, dilation)
+        g = _conv_geom(x.shape, w.shape, stride, padding, dilation, x_ld=x_ld)
         y = _conv_fwd(g, x, w, bias)
         ctx.save_for_backward(x, w)
         ctx.geom = g
@@ -219,12 +257,15 @@ class _Conv3dFn(torch.autograd.Function):
     def backward(ctx, dy):
         x, w = ctx.saved_tensors
         g = ctx.geom
-        dy = _cl(dy)
+        dy, y_ld = _nd(dy)
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
-            dx = _conv_dgrad(g, dy, w, None, x)
+            gd = _conv_geom(x.shape, w.shape, (g.sd, g.sh, g.sw), (g.pd, g.ph, g.pw), (g.dd, g.dh, g.dw), y_ld=y_ld)
+            dx = _conv_dgrad(gd, dy, w, None, x)       # dx is a fresh dense tensor (pitch = Cin)
         if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
-            dw, db = _conv_wgrad(g, x, dy, w, ctx.has_bias)
+            gw = _conv_geom(x.shape, w.shape, (g.sd, g.sh, g.sw), (g.pd, g.ph, g.pw), (g.dd, g.dh, g.dw), x_ld=g.x_ld,
+                            y_ld=y_ld)
+            dw, db = _conv_wgrad(gw, x, dy, w, ctx.has_bias)
         return dx, dw, db, None, None, None
 
 
@@ -299,16 +340,26 @@ class _NormActFn(torch.autograd.Function):
     """y = act(gamma * (x - mean) / sqrt(var + eps) + beta) with batch, instance, running or no statistics."""
 
     @staticmethod
-    def forward(ctx, x, gamma, beta, alpha, running_mean, running_var, stats_mode, momentum, eps, act, slope):
+    def forward(ctx, x, gamma, beta, alpha, running_mean, running_var, stats_mode, momentum, eps, act, slope, out):
         # stats_mode: "batch" (compute + update running), "instance", "running" (eval BN), "none" (activation only)
+        # out: None, or (buffer, channel_offset): write y into that channel slice of a wider NDHWC buffer
         _require_device(x, gamma, beta, alpha)
         L = _lib.lib()
-        x = _cl(x)
+        x, x_ld = _nd(x)
         n, c, d, h, w = x.shape
         act_code = _ACT_CODES[act]
         alpha_n = alpha.numel() if (act_code == ACT_PRELU) else 1
         instance = 1 if stats_mode == "instance" else 0
-        g = NormGeom(n, d * h * w, c, c, c, instance, act_code, alpha_n, float(slope), float(eps), F32)
+        if out is None:
+            y, y_ld, y_off = _new(x.shape, x), c, 0
+        else:
+            buf, y_off = out
+            y_ld = _pitch_of(buf)
+            if y_ld != buf.shape[1] or tuple(buf.shape[2:]) != (d, h, w) or buf.shape[0] != n or y_off + c > buf.shape[1]:
+                raise RuntimeError("norm_act(out=): buffer %s cannot hold a %s slice at channel %d"
+                                   % (tuple(buf.shape), tuple(x.shape), y_off))
+            y = _slice_view(buf, y_off, c)
+        g = NormGeom(n, d * h * w, c, x_ld, y_ld, instance, act_code, alpha_n, float(slope), float(eps), F32)
         mean = invstd = None
         if stats_mode in ("batch", "instance"):
             groups = n if instance else 1
@@ -323,7 +374,6 @@ class _NormActFn(torch.autograd.Function):
         elif stats_mode == "running":
             mean = running_mean.detach().to(torch.float32).contiguous()
             invstd = torch.rsqrt(running_var.detach().to(torch.float32) + eps).contiguous()
-        y = _new(x.shape, x)
         with _timed("norm_act_fwd c%d vox%d n%d" % (c, g.vox, n), {"flops": 0.0, "bytes": 8.0 * x.numel()}):
             check(L.mri3d_norm_act_fwd(ctypes.byref(g), _ptr(x), _ptr(mean), _ptr(invstd), _ptr(gamma), _ptr(beta),
                                        _ptr(alpha) if act_code == ACT_PRELU else None, _ptr(y), _stream()),
@@ -337,9 +387,13 @@ class _NormActFn(torch.autograd.Function):
     def backward(ctx, dy):
         L = _lib.lib()
         x, mean, invstd, gamma, beta, alpha = ctx.saved_tensors
-        g = ctx.geom
-        dy = _cl(dy)
-        dx = _new(x.shape, x)
+        g0 = ctx.geom
+        dy, dy_ld = _nd(dy)
+        dx = _new(x.shape, x) if g0.x_ld == g0.c else None
+        if dx is None:  # dx shares x's pitch in the kernel: give it a dense x instead
+            x = x.contiguous(memory_format=CL3D)
+            dx = _new(x.shape, x)
+        g = NormGeom(g0.n, g0.vox, g0.c, g0.c, dy_ld, g0.instance, g0.act, g0.alpha_n, g0.slope, g0.eps, F32)
         dgamma = torch.empty_like(gamma) if (gamma is not None and ctx.needs_input_grad[1]) else None
         dbeta = torch.empty_like(beta) if (beta is not None and ctx.needs_input_grad[2]) else None
         prelu = g.act == ACT_PRELU
@@ -350,14 +404,14 @@ class _NormActFn(torch.autograd.Function):
                                        _ptr(invstd), _ptr(gamma), _ptr(beta), _ptr(alpha) if prelu else None, _ptr(dx),
                                        _ptr(dgamma), _ptr(dbeta), _ptr(dalpha), _ptr(ws), ws.numel(), _stream()),
                   "norm_act_bwd")
-        return dx, dgamma, dbeta, dalpha, None, None, None, None, None, None, None
+        return dx, dgamma, dbeta, dalpha, None, None, None, None, None, None, None, None
 
 
 def norm_act(x, gamma=None, beta=None, alpha=None, running_mean=None, running_var=None, stats_mode="batch",
-             momentum=0.1, eps=1e-5, act=None, slope=0.01):
+             momentum=0.1, eps=1e-5, act=None, slope=0.01, out=None):
     if momentum is None:
         raise RuntimeError("cumulative moving average (momentum=None) is not supported")
-    return _NormActFn.apply(x, gamma, beta, alpha, running_mean, running_var, stats_mode, momentum, eps, act, slope)
+    return _NormActFn.apply(x, gamma, beta, alpha, running_mean, running_var, stats_mode, momentum, eps, act, slope, out)
 
 
 def activation(x, act, alpha=None, slope=0.01):
@@ -421,12 +475,12 @@ class _MaxPool3dFn(torch.autograd.Function):
     def forward(ctx, x, kernel, stride, padding):
         _require_device(x)
         L = _lib.lib()
-        x = _cl(x)
+        x, x_ld = _nd(x)
         n, c, d, h, w = x.shape
         do, ho, wo = (_pool_out(i, k, s, p, False) for i, k, s, p in zip((d, h, w), kernel, stride, padding))
         if do <= 0 or ho <= 0 or wo <= 0:
             raise RuntimeError("max_pool3d: output size is too small (input %s, kernel %s)" % ((d, h, w), kernel))
-        g = PoolGeom(n, d, h, w, do, ho, wo, c, *kernel, *stride, *padding, c, c, F32)
+        g = PoolGeom(n, d, h, w, do, ho, wo, c, *kernel, *stride, *padding, x_ld, c, F32)
         y = _new((n, c, do, ho, wo), x)
         idx = torch.empty(n * do * ho * wo * c, dtype=torch.uint8, device=x.device)
         with _timed("maxpool_fwd c%d" % c, {"flops": 0.0, "bytes": 4.0 * x.numel() + 5.0 * y.numel()}):
@@ -440,11 +494,13 @@ class _MaxPool3dFn(torch.autograd.Function):
     def backward(ctx, dy):
         L = _lib.lib()
         (idx,) = ctx.saved_tensors
-        dy = _cl(dy)
+        dy, dy_ld = _nd(dy)
         dx = _new(ctx.xshape, dy)
-        with _timed("maxpool_bwd c%d" % ctx.geom.c, {"flops": 0.0, "bytes": 4.0 * dx.numel() + 5.0 * dy.numel()}):
-            check(L.mri3d_maxpool3d_bwd(ctypes.byref(ctx.geom), _ptr(dy), _ptr(idx), _ptr(dx), _stream()),
-                  "maxpool3d_bwd")
+        g0 = ctx.geom
+        g = PoolGeom(g0.n, g0.di, g0.hi, g0.wi, g0.dout, g0.ho, g0.wo, g0.c, g0.kd, g0.kh, g0.kw, g0.sd, g0.sh, g0.sw,
+                     g0.pd, g0.ph, g0.pw, g0.c, dy_ld, F32)
+        with _timed("maxpool_bwd c%d" % g.c, {"flops": 0.0, "bytes": 4.0 * dx.numel() + 5.0 * dy.numel()}):
+            check(L.mri3d_maxpool3d_bwd(ctypes.byref(g), _ptr(dy), _ptr(idx), _ptr(dx), _stream()), "maxpool3d_bwd")
         return dx, None, None, None
 
 
@@ -459,14 +515,23 @@ def max_pool3d(x, kernel_size, stride=None, padding=0):
 
 class _Upsample3dFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, out_size, mode, align_corners, ratios):
+    def forward(ctx, x, out_size, mode, align_corners, ratios, out):
         _require_device(x)
         L = _lib.lib()
-        x = _cl(x)
+        x, x_ld = _nd(x)
         n, c, d, h, w = x.shape
         do, ho, wo = out_size
-        g = UpGeom(n, d, h, w, do, ho, wo, c, c, c, mode, 1 if align_corners else 0, ratios[0], ratios[1], ratios[2], F32)
-        y = _new((n, c, do, ho, wo), x)
+        if out is None:
+            y, y_ld = _new((n, c, do, ho, wo), x), c
+        else:
+            buf, y_off = out
+            y_ld = _pitch_of(buf)
+            if y_ld != buf.shape[1] or tuple(buf.shape[2:]) != (do, ho, wo) or buf.shape[0] != n or y_off + c > buf.shape[1]:
+                raise RuntimeError("upsample3d(out=): buffer %s cannot hold a %s slice at channel %d"
+                                   % (tuple(buf.shape), (n, c, do, ho, wo), y_off))
+            y = _slice_view(buf, y_off, c)
+        g = UpGeom(n, d, h, w, do, ho, wo, c, x_ld, y_ld, mode, 1 if align_corners else 0, ratios[0], ratios[1], ratios[2],
+                   F32)
         with _timed("upsample_fwd c%d" % c, {"flops": 0.0, "bytes": 4.0 * (x.numel() + y.numel())}):
             check(L.mri3d_upsample3d_fwd(ctypes.byref(g), _ptr(x), _ptr(y), _stream()), "upsample3d_fwd")
         ctx.geom = g
@@ -476,17 +541,19 @@ class _Upsample3dFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy):
         L = _lib.lib()
-        g = ctx.geom
-        dy = _cl(dy)
+        g0 = ctx.geom
+        dy, dy_ld = _nd(dy)
         dx = _new(ctx.xshape, dy)
+        g = UpGeom(g0.n, g0.di, g0.hi, g0.wi, g0.dout, g0.ho, g0.wo, g0.c, g0.c, dy_ld, g0.mode, g0.align_corners, g0.rd,
+                   g0.rh, g0.rw, F32)
         ws = _workspace(L.mri3d_upsample3d_workspace_bytes(ctypes.byref(g)), dy.device)
         with _timed("upsample_bwd c%d" % g.c, {"flops": 0.0, "bytes": 4.0 * (dx.numel() + dy.numel())}):
             check(L.mri3d_upsample3d_bwd(ctypes.byref(g), _ptr(dy), _ptr(dx), _ptr(ws), ws.numel(), _stream()),
                   "upsample3d_bwd")
-        return dx, None, None, None, None
+        return dx, None, None, None, None, None
 
 
-def upsample3d(x, size=None, scale_factor=None, mode="nearest", align_corners=None):
+def upsample3d(x, size=None, scale_factor=None, mode="nearest", align_corners=None, out=None):
     """torch.nn.functional.interpolate semantics for 5-D input, modes 'nearest' and 'trilinear'."""
     if mode == "linear":
         mode = "trilinear"
@@ -498,15 +565,15 @@ def upsample3d(x, size=None, scale_factor=None, mode="nearest", align_corners=No
     if (size is None) == (scale_factor is None):
         raise ValueError("exactly one of size or scale_factor must be given")
     if size is not None:
-        out = _triple(size)
+        out_sz = _triple(size)
         sf = None
     else:
         sf = tuple(float(s) for s in (scale_factor if isinstance(scale_factor, (tuple, list)) else (scale_factor,) * 3))
-        out = tuple(int(math.floor(float(i) * s)) for i, s in zip(in_sz, sf))
+        out_sz = tuple(int(math.floor(float(i) * s)) for i, s in zip(in_sz, sf))
     ac = bool(align_corners)
     ratios = []
     for a in range(3):
-        i, o = in_sz[a], out[a]
+        i, o = in_sz[a], out_sz[a]
         if mode == "trilinear" and ac:
             r = (i - 1) / (o - 1) if o > 1 else 0.0
         elif sf is not None:
@@ -515,7 +582,7 @@ def upsample3d(x, size=None, scale_factor=None, mode="nearest", align_corners=No
             r = i / o
         ratios.append(float(r))
     code = UP_NEAREST if mode == "nearest" else UP_TRILINEAR
-    return _Upsample3dFn.apply(x, out, code, ac, tuple(ratios))
+    return _Upsample3dFn.apply(x, out_sz, code, ac, tuple(ratios), out)
 
 
 # ----------------------------------------------------------------------------------------------- loss
@@ -615,6 +682,44 @@ class _CatFn(torch.autograd.Function):
 
 def cat_channels(xs):
     return _CatFn.apply(*xs)
+
+
+def new_cat_buffer(n, channels, spatial, like):
+    """Uninitialised NDHWC buffer that producers fill slice by slice (norm_act(out=), upsample3d(out=))."""
+    return torch.empty((n, channels, *spatial), dtype=like.dtype, device=like.device, memory_format=CL3D)
+
+
+class _JoinFn(torch.autograd.Function):
+    """torch.cat(dim=1) WITHOUT the copy: the parts are channel-slice views that their producers already wrote into
+    `buf`; forward hands out the buffer, backward hands each producer its slice of the gradient (views, no copy)."""
+
+    @staticmethod
+    def forward(ctx, buf, *parts):
+        off = 0
+        for p in parts:
+            c = p.shape[1]
+            if p.data_ptr() != buf.data_ptr() + off * buf.element_size() or _pitch_of(p) != buf.shape[1]:
+                raise RuntimeError("join_channels: part is not the [%d:%d) channel slice of the buffer" % (off, off + c))
+            off += c
+        if off != buf.shape[1]:
+            raise RuntimeError("join_channels: parts cover %d of %d channels" % (off, buf.shape[1]))
+        ctx.chans = [p.shape[1] for p in parts]
+        return buf.view_as(buf)
+
+    @staticmethod
+    def backward(ctx, dcat):
+        dcat, _ = _nd(dcat)
+        if _pitch_of(dcat) != dcat.shape[1]:
+            dcat = dcat.contiguous(memory_format=CL3D)
+        outs, off = [None], 0
+        for c in ctx.chans:
+            outs.append(_slice_view(dcat, off, c))
+            off += c
+        return tuple(outs)
+
+
+def join_channels(buf, parts):
+    return _JoinFn.apply(buf, *parts)
 
 
 class _AddFn(torch.autograd.Function):

@@ -44,8 +44,8 @@ class ConvolutionalBlock(tnn.Module):
         self.dropout_layer = None
         self.block = tnn.Sequential(*[m for m in (conv, norm, act) if m is not None])
 
-    def forward(self, x):
-        return mnn.fused_norm_act(self.norm_layer, self.activation_layer, self.conv_layer(x))
+    def forward(self, x, out=None):
+        return mnn.fused_norm_act(self.norm_layer, self.activation_layer, self.conv_layer(x), out)
 
 
 class EncodingBlock(tnn.Module):
@@ -67,8 +67,9 @@ class EncodingBlock(tnn.Module):
                 raise NotImplementedError("only max pooling is used by the reference")
             self.downsample = mnn.MaxPool3d(kernel_size=2)
 
-    def forward(self, x):
-        x = self.conv2(self.conv1(x))
+    def forward(self, x, skip_out=None):
+        # skip_out = (concat buffer, 0): the block's output is written straight into the decoder's concat buffer
+        x = self.conv2(self.conv1(x), skip_out)
         if self.downsample is None:
             return x
         return self.downsample(x), x
@@ -95,10 +96,10 @@ class Encoder(tnn.Module):
             if self.dilation is not None:
                 self.dilation *= 2
 
-    def forward(self, x):
+    def forward(self, x, cat_bufs=None):
         skips = []
-        for blk in self.encoding_blocks:
-            x, skip = blk(x)
+        for i, blk in enumerate(self.encoding_blocks):
+            x, skip = blk(x, None if cat_bufs is None else (cat_bufs[i], 0))
             skips.append(skip)
         return skips, x
 
@@ -124,11 +125,18 @@ class DecodingBlock(tnn.Module):
                                         normalization=normalization, padding=padding, activation=activation,
                                         dilation=dilation)
 
-    def forward(self, skip, x):
-        x = self.upsample(x)
-        if skip.shape[2:] != x.shape[2:]:
-            raise NotImplementedError("padding=False (centre-cropped skips) is not used by the reference")
-        x = ops.cat_channels([skip, x])  # skip first: SURVEY.md A.3
+    def forward(self, skip, x, cat_buf=None):
+        if cat_buf is not None and isinstance(self.upsample, mnn.Upsample):
+            # copy-free torch.cat((skip, up)): `skip` already lives in cat_buf[:, :Cs]; the upsample kernel writes
+            # cat_buf[:, Cs:]; join_channels only ties the two producers together for autograd (skip first: SURVEY A.3)
+            up = ops.upsample3d(x, self.upsample.size, self.upsample.scale_factor, self.upsample.mode,
+                                self.upsample.align_corners, out=(cat_buf, skip.shape[1]))
+            x = ops.join_channels(cat_buf, [skip, up])
+        else:
+            x = self.upsample(x)
+            if skip.shape[2:] != x.shape[2:]:
+                raise NotImplementedError("padding=False (centre-cropped skips) is not used by the reference")
+            x = ops.cat_channels([skip, x])
         return self.conv2(self.conv1(x))
 
 
@@ -146,9 +154,9 @@ class Decoder(tnn.Module):
             if self.dilation is not None:
                 self.dilation //= 2
 
-    def forward(self, skips, x):
-        for skip, blk in zip(reversed(skips), self.decoding_blocks):
-            x = blk(skip, x)
+    def forward(self, skips, x, cat_bufs=None):
+        for j, (skip, blk) in enumerate(zip(reversed(skips), self.decoding_blocks)):
+            x = blk(skip, x, None if cat_bufs is None else cat_bufs[len(skips) - 1 - j])
         return x
 
 
@@ -180,7 +188,19 @@ class UNet(tnn.Module):
                                              activation=None)
 
     def forward(self, x):
-        skips, enc = self.encoder(x)
+        # One NDHWC buffer per level holds cat((skip, upsampled)); both producers write their channel slice in place.
+        cat_bufs = None
+        if x.is_cuda and len(self.encoder.encoding_blocks) and all(
+                isinstance(b.upsample, mnn.Upsample) for b in self.decoder.decoding_blocks):
+            cat_bufs = []
+            n, sp = x.shape[0], tuple(x.shape[2:])
+            for blk in self.encoder.encoding_blocks:
+                if any(s % 2 for s in sp):
+                    cat_bufs = None
+                    break
+                cat_bufs.append(ops.new_cat_buffer(n, 3 * blk.out_channels, sp, x))
+                sp = tuple(s // 2 for s in sp)
+        skips, enc = self.encoder(x, cat_bufs)
         enc = self.bottom_block(enc)
-        x = self.decoder(skips, enc)
+        x = self.decoder(skips, enc, cat_bufs)
         return self.classifier(x)

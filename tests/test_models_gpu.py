@@ -39,7 +39,7 @@ def _step(model, x, loss_fn, train):
     return out.detach(), loss.detach()
 
 
-def _compare(prod, orc, x, loss_prod, loss_orc, train, gold=None, rel=1e-3, grad_rel=1e-2):
+def _compare(prod, orc, x, loss_prod, loss_orc, train, gold=None, rel=1e-3, grad_rel=3e-2):
     """prod on GPU vs orc on CPU on the same input; optionally also vs the golden record."""
     prod.load_state_dict(orc.state_dict())
     prod.to(DEV)
@@ -54,7 +54,10 @@ def _compare(prod, orc, x, loss_prod, loss_orc, train, gold=None, rel=1e-3, grad
     # kernels are as accurate as torch's fp32 CPU kernels (tools/op_error_audit.py: 1e-7..2e-6 either way), but a
     # gradient that has travelled back through ten normalisation layers carries those 1e-6 perturbations amplified by
     # the cancellation in sum(du * xhat): both fp32 paths land 1e-4..1e-2 from the fp64 truth, tensor by tensor.
-    # So: the HIP gradient must be within grad_rel (1e-2, max-norm per tensor) of the truth
+    # On top of that the models are NOT smooth: max-pool arg-max near-ties and PReLU kinks flip under a 1e-6 input
+    # perturbation and move individual gradient tensors by 1e-2 even in exact arithmetic
+    # (tests/test_oracle_golden.py::test_reference_gradients_are_discontinuous_at_fp32_noise_level).
+    # So: the HIP gradient must be within grad_rel (3e-2, max-norm per tensor) of the truth
     # (max-norm, per tensor) OR no further from it than 4x what PyTorch's own fp32 CPU path (the reference's
     # arithmetic) is.  The second clause covers tensors whose true gradient is zero by construction (a conv bias feeding
     # a train-mode BatchNorm), where every fp32 implementation returns rounding noise.
@@ -232,7 +235,7 @@ def test_cnn_family_train_step(name, cls, kw, shape):
     x = seeded_randn(21, shape)
     y = torch.arange(shape[0]) % 2
     _compare(prod, orc, x, lambda o: F.cross_entropy(o[:, :2], y.to(DEV)), lambda o: F.cross_entropy(o[:, :2], y), True,
-             gold=load_golden(name + ".npz"), grad_rel=1e-2)
+             gold=load_golden(name + ".npz"), grad_rel=3e-2)
 
 
 # ------------------------------------------------------------------------------------------------ Modified3DUNet
@@ -243,7 +246,7 @@ def test_modified3dunet_eval_step():
     x = seeded_randn(11, (1, 1, 32, 32, 32))
     tgt = (seeded_rand(12, (1, 1, 32, 32, 32)) < 0.2).float()
     _compare(prod, orc, x, lambda o: ops.softmax_dice_loss(o, tgt.to(DEV)), lambda o: losses.softmax_dice_loss(o, tgt.to(o.dtype)), False,
-             gold=load_golden("modified3dunet_b8_32.npz"), grad_rel=1e-2)
+             gold=load_golden("modified3dunet_b8_32.npz"), grad_rel=3e-2)
 
 
 def test_modified3dunet_train_mode_runs_with_dropout():

@@ -35,5 +35,5 @@ def test_unet_gradients_vs_fp64_truth(c0):
         e_cpu = (p32.grad.double() - p64.grad).abs().max().item() / den
         e_hip = (pp.grad.cpu().double() - p64.grad).abs().max().item() / den
         worst_cpu, worst_hip = max(worst_cpu, e_cpu), max(worst_hip, e_hip)
-        assert e_hip <= max(1e-2, 4.0 * e_cpu), "%s: HIP err %.2e vs fp64, CPU-fp32 err %.2e" % (k, e_hip, e_cpu)
+        assert e_hip <= max(3e-2, 4.0 * e_cpu), "%s: HIP err %.2e vs fp64, CPU-fp32 err %.2e" % (k, e_hip, e_cpu)
     print("worst grad error vs fp64: torch-CPU-fp32 %.2e, HIP %.2e" % (worst_cpu, worst_hip))
