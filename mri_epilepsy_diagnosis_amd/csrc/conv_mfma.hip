@@ -530,7 +530,8 @@ __device__ __forceinline__ int wg_tap_offset(int tap) {  // halo-voxel offset of
 template <int CK, bool BIAS>
 __global__ void __launch_bounds__(256, 2)
 conv_mfma_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ part, int N, int D,
-                       int H, int W, int Ci, int x_ld, int Co, int y_ld, int tilesD, int tilesH, int tilesW, int ntiles) {
+                       int H, int W, int Ci, int x_ld, int Co, int y_ld, int tilesD, int tilesH, int tilesW, int ntiles,
+                       int ablate) {
     constexpr int TG = wg_tap_groups(CK);
     constexpr int TGA = TG + (BIAS ? 1 : 0);
     constexpr int CP = CK;           // X tile voxel pitch (floats)
@@ -573,6 +574,7 @@ conv_mfma_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ dy
         const float* dn = dy + (int64_t)n * D * H * W * y_ld + cob * 16;
 
         __syncthreads();
+        if (!(ablate & 1))
         for (int idx = tid; idx < WHVOX * XQ; idx += 256) {
             const int q = idx % XQ, v = idx / XQ;
             const int wx = v % WHW;
@@ -588,6 +590,7 @@ conv_mfma_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ dy
                 xs[v * CP + q] = ok ? *src : 0.f;
             }
         }
+        if (!(ablate & 1))
         for (int idx = tid; idx < WVOX * 4; idx += 256) {
             const int q = idx & 3, v = idx >> 2;
             const int wx = v % WTW;
@@ -612,6 +615,7 @@ conv_mfma_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ dy
         }
         __syncthreads();
 
+        if (ablate & 2) continue;
 #pragma unroll 1
         for (int hr = 0; hr < 4; ++hr) {
             const int hy = hsel * 4 + hr;
@@ -627,6 +631,299 @@ conv_mfma_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ dy
                 }
                 if (BIAS) acc[TG] = __builtin_amdgcn_mfma_f32_16x16x4f32(1.0f, b, acc[TG], 0, 0, 0);
             }
+        }
+    }
+
+    // combine the 4 waves in a fixed order through LDS, then one partial per workgroup
+    __syncthreads();
+    float* red = lds;  // [TGA][256]
+    for (int w = 0; w < 4; ++w) {
+        if (wv == w) {
+#pragma unroll
+            for (int t = 0; t < TGA; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int o = t * 256 + (4 * kq + r) * 16 + li;
+                    red[o] = (w == 0) ? acc[t][r] : red[o] + acc[t][r];
+                }
+        }
+        __syncthreads();
+    }
+    float* out = part + (((size_t)blockIdx.x * gridDim.y + cit) * gridDim.z + cob) * (TGA * 256);
+    for (int i = tid; i < TGA * 256; i += 256) out[i] = red[i];
+}
+
+// ------------------------------------------------------------------ weight gradient, version 3 (CK = 16 or 8)
+// v1 spends 2.3 of 5.1 ms of the 48->16 layer staging tiles while no MFMA runs (ablation: compute-only 130 TFLOP/s);
+// the two resident workgroups of a CU run in lock-step, so nothing hides it.  v3 keeps v1's compute (all tap-group
+// accumulators in registers, conflict-free 16-row M-tiles) and splits the staging T14-style: the NEXT tile's 16-byte
+// pieces (12 of X + 4 of dY per lane) are fetched into registers before the current tile's 432 MFMAs per wave and
+// written to LDS after them, so HBM/L2 latency is covered by MFMA work and only the LDS write pass stays exposed.
+template <int CK, bool BIAS>
+__global__ void __launch_bounds__(256, 2)
+conv_mfma_wgrad3_kernel(const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ part, int N, int D,
+                        int H, int W, int Ci, int x_ld, int Co, int y_ld, int tilesD, int tilesH, int tilesW, int ntiles) {
+    constexpr int TG = wg_tap_groups(CK);
+    constexpr int TGA = TG + (BIAS ? 1 : 0);
+    constexpr int CP = CK;
+    constexpr int XQ = CK / 4;
+    constexpr int NPX = (WHVOX * XQ + 255) / 256;  // X pieces per lane (12 for CK=16, 6 for CK=8)
+    constexpr int NPY = WVOX * 4 / 256;            // dY pieces per lane (4)
+    constexpr int XBUF = NPX * 256 * 4;            // floats (padded to whole pieces)
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* xs = lds;           // [WHVOX][CP] (+ padding)
+    float* dys = lds + XBUF;   // [WVOX][16]
+
+    const int cit = blockIdx.y, cob = blockIdx.z;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int li = lane & 15, kq = lane >> 4;
+    const int dsel = wv >> 1, hsel = wv & 1;
+
+    f32x4 acc[TGA];
+#pragma unroll
+    for (int t = 0; t < TGA; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    int lane_aoff[TG];
+#pragma unroll
+    for (int tg = 0; tg < TG; ++tg) {
+        if (CK == 16) lane_aoff[tg] = wg_tap_offset<CK>(tg) * CP + li;
+        else lane_aoff[tg] = wg_tap_offset<CK>(2 * tg + (li >> 3)) * CP + (li & 7);
+    }
+
+    struct Tile { int n, d0, h0, w0; };
+    auto decode = [&](int tile) -> Tile {
+        Tile r;
+        r.w0 = (tile % tilesW) * WTW;
+        tile /= tilesW;
+        r.h0 = (tile % tilesH) * WTH;
+        tile /= tilesH;
+        r.d0 = (tile % tilesD) * WTD;
+        r.n = tile / tilesD;
+        return r;
+    };
+    float4 px[NPX], py[NPY];
+    unsigned xok = 0, yok = 0;
+    // unconditional (clamped) loads; out-of-volume pieces are zeroed when they are written to LDS
+    auto load_tile = [&](const Tile& t) {
+#pragma unroll
+        for (int j = 0; j < NPX; ++j) {
+            const int idx = j * 256 + tid;
+            const int pv = idx < WHVOX * XQ ? idx : 0;
+            const int q = pv % XQ, v = pv / XQ;
+            const int wx = v % WHW, t2 = v / WHW;
+            const int gd = t.d0 - 1 + t2 / WHH, gh = t.h0 - 1 + t2 % WHH, gw = t.w0 - 1 + wx;
+            const bool ok = (unsigned)gd < (unsigned)D && (unsigned)gh < (unsigned)H && (unsigned)gw < (unsigned)W;
+            xok = ok ? (xok | (1u << j)) : (xok & ~(1u << j));
+            const int cd = min(max(gd, 0), D - 1), chh = min(max(gh, 0), H - 1), cw = min(max(gw, 0), W - 1);
+            px[j] = *reinterpret_cast<const float4*>(x + ((((int64_t)t.n * D + cd) * H + chh) * W + cw) * x_ld + cit * CK +
+                                                     4 * q);
+        }
+#pragma unroll
+        for (int j = 0; j < NPY; ++j) {
+            const int idx = j * 256 + tid;
+            const int q = idx & 3, v = idx >> 2;
+            const int wx = v % WTW, t2 = v / WTW;
+            const int gd = t.d0 + t2 / WTH, gh = t.h0 + t2 % WTH, gw = t.w0 + wx;
+            const int cb = cob * 16 + 4 * q;
+            const bool ok = gd < D && gh < H && gw < W && cb < Co;   // host guarantees Co % 4 == 0
+            yok = ok ? (yok | (1u << j)) : (yok & ~(1u << j));
+            const int cd = min(gd, D - 1), chh = min(gh, H - 1), cw = min(gw, W - 1), cc = min(cb, Co - 4);
+            py[j] = *reinterpret_cast<const float4*>(dy + ((((int64_t)t.n * D + cd) * H + chh) * W + cw) * y_ld + cc);
+        }
+    };
+    auto store_tile = [&]() {
+#pragma unroll
+        for (int j = 0; j < NPX; ++j) {
+            const bool ok = (xok >> j) & 1u;
+            float4 v2;
+            v2.x = ok ? px[j].x : 0.f; v2.y = ok ? px[j].y : 0.f; v2.z = ok ? px[j].z : 0.f; v2.w = ok ? px[j].w : 0.f;
+            *reinterpret_cast<float4*>(xs + (j * 256 + tid) * 4) = v2;
+        }
+#pragma unroll
+        for (int j = 0; j < NPY; ++j) {
+            const bool ok = (yok >> j) & 1u;
+            float4 v2;
+            v2.x = ok ? py[j].x : 0.f; v2.y = ok ? py[j].y : 0.f; v2.z = ok ? py[j].z : 0.f; v2.w = ok ? py[j].w : 0.f;
+            *reinterpret_cast<float4*>(dys + (j * 256 + tid) * 4) = v2;
+        }
+    };
+
+    const int P = gridDim.x;
+    const int t_lo = (int)(((int64_t)ntiles * blockIdx.x) / P), t_hi = (int)(((int64_t)ntiles * (blockIdx.x + 1)) / P);
+    if (t_hi > t_lo) {
+        load_tile(decode(t_lo));
+        store_tile();
+        __syncthreads();
+        for (int tile = t_lo; tile < t_hi; ++tile) {
+            const bool has_next = tile + 1 < t_hi;
+            if (has_next) load_tile(decode(tile + 1));   // global -> registers, in flight during the MFMAs below
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll 1
+            for (int hr = 0; hr < 4; ++hr) {
+                const int hy = hsel * 4 + hr;
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) {
+                    const int wx = ks * 4 + kq;
+                    const float b = dys[((dsel * WTH + hy) * WTW + wx) * 16 + li];
+                    const float* abase = xs + ((dsel * WHH + hy) * WHW + wx) * CP;
+#pragma unroll
+                    for (int tg = 0; tg < TG; ++tg) {
+                        const float a = abase[lane_aoff[tg]];
+                        acc[tg] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc[tg], 0, 0, 0);
+                    }
+                    if (BIAS) acc[TG] = __builtin_amdgcn_mfma_f32_16x16x4f32(1.0f, b, acc[TG], 0, 0, 0);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            __syncthreads();                 // every wave is done reading this tile
+            if (has_next) store_tile();      // registers -> LDS
+            __syncthreads();
+        }
+    }
+
+    // combine the 4 waves in a fixed order through LDS, then one partial per workgroup
+    __syncthreads();
+    float* red = lds;  // [TGA][256]
+    for (int w = 0; w < 4; ++w) {
+        if (wv == w) {
+#pragma unroll
+            for (int t = 0; t < TGA; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int o = t * 256 + (4 * kq + r) * 16 + li;
+                    red[o] = (w == 0) ? acc[t][r] : red[o] + acc[t][r];
+                }
+        }
+        __syncthreads();
+    }
+    float* out = part + (((size_t)blockIdx.x * gridDim.y + cit) * gridDim.z + cob) * (TGA * 256);
+    for (int i = tid; i < TGA * 256; i += 256) out[i] = red[i];
+}
+
+// ------------------------------------------------------------------ weight gradient, version 4 (Cin % 16 == 0)
+// v3's overlap without its register bill: a 2x4x16-voxel tile (X halo 27 KB + dY 8 KB) is small enough to double-buffer
+// in LDS with two workgroups per CU, and its 9 pieces per lane fit in registers next to the 27 tap accumulators.
+// Per tile every wave runs 2 h-rows x 4 k-steps x 27 MFMAs: the next tile's pieces are fetched during row 0 and written
+// to the OTHER buffer during row 1 — no exposed staging pass and a single barrier per tile.
+constexpr int V4TH = 4, V4HH = V4TH + 2;
+constexpr int V4HVOX = WHD * V4HH * WHW;           // 4 x 6 x 18 = 432 halo voxels
+constexpr int V4VOX = WTD * V4TH * WTW;            // 128 output voxels
+constexpr int V4NPX = (V4HVOX * 4 + 255) / 256;    // 7 X pieces per lane
+constexpr int V4NPY = V4VOX * 4 / 256;             // 2 dY pieces per lane
+constexpr int V4XBUF = V4NPX * 256 * 4;            // floats
+constexpr int V4YBUF = V4VOX * 16;                 // floats
+
+__device__ __forceinline__ int v4_tap_offset(int tap) { return ((tap / 9) * V4HH + (tap / 3) % 3) * WHW + tap % 3; }
+
+template <bool BIAS>
+__global__ void __launch_bounds__(256, 2)
+conv_mfma_wgrad4_kernel(const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ part, int N, int D,
+                        int H, int W, int Ci, int x_ld, int Co, int y_ld, int tilesD, int tilesH, int tilesW, int ntiles) {
+    constexpr int TG = 27, TGA = TG + (BIAS ? 1 : 0), CP = 16;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* xs = lds;                    // [2][V4XBUF]
+    float* dys = lds + 2 * V4XBUF;      // [2][V4YBUF]
+
+    const int cit = blockIdx.y, cob = blockIdx.z;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int li = lane & 15, kq = lane >> 4;
+    const int dsel = wv >> 1, hsel = wv & 1;
+
+    f32x4 acc[TGA];
+#pragma unroll
+    for (int t = 0; t < TGA; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    struct Tile { int n, d0, h0, w0; };
+    auto decode = [&](int tile) -> Tile {
+        Tile r;
+        r.w0 = (tile % tilesW) * WTW;
+        tile /= tilesW;
+        r.h0 = (tile % tilesH) * V4TH;
+        tile /= tilesH;
+        r.d0 = (tile % tilesD) * WTD;
+        r.n = tile / tilesD;
+        return r;
+    };
+    float4 px[V4NPX], py[V4NPY];
+    unsigned xok = 0, yok = 0;
+    auto load_tile = [&](const Tile& t) {   // unconditional clamped loads; zeroing happens at store time
+#pragma unroll
+        for (int j = 0; j < V4NPX; ++j) {
+            const int idx = j * 256 + tid;
+            const int pv = idx < V4HVOX * 4 ? idx : 0;
+            const int q = pv & 3, v = pv >> 2;
+            const int wx = v % WHW, t2 = v / WHW;
+            const int gd = t.d0 - 1 + t2 / V4HH, gh = t.h0 - 1 + t2 % V4HH, gw = t.w0 - 1 + wx;
+            const bool ok = (unsigned)gd < (unsigned)D && (unsigned)gh < (unsigned)H && (unsigned)gw < (unsigned)W;
+            xok = ok ? (xok | (1u << j)) : (xok & ~(1u << j));
+            const int cd = min(max(gd, 0), D - 1), chh = min(max(gh, 0), H - 1), cw = min(max(gw, 0), W - 1);
+            px[j] = *reinterpret_cast<const float4*>(x + ((((int64_t)t.n * D + cd) * H + chh) * W + cw) * x_ld + cit * 16 +
+                                                     4 * q);
+        }
+#pragma unroll
+        for (int j = 0; j < V4NPY; ++j) {
+            const int idx = j * 256 + tid;
+            const int q = idx & 3, v = idx >> 2;
+            const int wx = v % WTW, t2 = v / WTW;
+            const int gd = t.d0 + t2 / V4TH, gh = t.h0 + t2 % V4TH, gw = t.w0 + wx;
+            const int cb = cob * 16 + 4 * q;
+            const bool ok = gd < D && gh < H && gw < W && cb < Co;   // host guarantees Co % 4 == 0
+            yok = ok ? (yok | (1u << j)) : (yok & ~(1u << j));
+            const int cd = min(gd, D - 1), chh = min(gh, H - 1), cw = min(gw, W - 1), cc = min(cb, Co - 4);
+            py[j] = *reinterpret_cast<const float4*>(dy + ((((int64_t)t.n * D + cd) * H + chh) * W + cw) * y_ld + cc);
+        }
+    };
+    auto store_tile = [&](float* xb, float* yb) {
+#pragma unroll
+        for (int j = 0; j < V4NPX; ++j) {
+            const bool ok = (xok >> j) & 1u;
+            float4 v2;
+            v2.x = ok ? px[j].x : 0.f; v2.y = ok ? px[j].y : 0.f; v2.z = ok ? px[j].z : 0.f; v2.w = ok ? px[j].w : 0.f;
+            *reinterpret_cast<float4*>(xb + (j * 256 + tid) * 4) = v2;
+        }
+#pragma unroll
+        for (int j = 0; j < V4NPY; ++j) {
+            const bool ok = (yok >> j) & 1u;
+            float4 v2;
+            v2.x = ok ? py[j].x : 0.f; v2.y = ok ? py[j].y : 0.f; v2.z = ok ? py[j].z : 0.f; v2.w = ok ? py[j].w : 0.f;
+            *reinterpret_cast<float4*>(yb + (j * 256 + tid) * 4) = v2;
+        }
+    };
+    auto row = [&](const float* xb, const float* yb, int hr) {
+        const int hy = hsel * 2 + hr;
+        // a REAL loop over the 4 k-steps (one basic block each): unrolled, hipcc hoists all four k-steps' LDS reads
+        // (108 VGPRs) on top of the 112 accumulators + 36 staging registers and spills (78 vs 96 TFLOP/s measured)
+#pragma unroll 1
+        for (int ks = 0; ks < 4; ++ks) {
+            const int wx = ks * 4 + kq;
+            const float b = yb[((dsel * V4TH + hy) * WTW + wx) * 16 + li];
+            const float* abase = xb + ((dsel * V4HH + hy) * WHW + wx) * CP + li;
+#pragma unroll
+            for (int tg = 0; tg < TG; ++tg) {
+                const float a = abase[v4_tap_offset(tg) * CP];
+                acc[tg] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc[tg], 0, 0, 0);
+            }
+            if (BIAS) acc[TG] = __builtin_amdgcn_mfma_f32_16x16x4f32(1.0f, b, acc[TG], 0, 0, 0);
+        }
+    };
+
+    const int P = gridDim.x;
+    const int t_lo = (int)(((int64_t)ntiles * blockIdx.x) / P), t_hi = (int)(((int64_t)ntiles * (blockIdx.x + 1)) / P);
+    if (t_hi > t_lo) {
+        load_tile(decode(t_lo));
+        store_tile(xs, dys);
+        __syncthreads();
+        for (int tile = t_lo; tile < t_hi; ++tile) {
+            const int cb = (tile - t_lo) & 1;
+            const float* xb = xs + cb * V4XBUF;
+            const float* yb = dys + cb * V4YBUF;
+            const bool has_next = tile + 1 < t_hi;
+            if (has_next) load_tile(decode(tile + 1));        // global -> registers
+            __builtin_amdgcn_sched_barrier(0);
+            row(xb, yb, 0);                                   // 108 MFMAs per wave cover the loads
+            if (has_next) store_tile(xs + (cb ^ 1) * V4XBUF, dys + (cb ^ 1) * V4YBUF);  // registers -> the OTHER buffer
+            row(xb, yb, 1);
+            __syncthreads();
         }
     }
 
@@ -687,7 +984,7 @@ wgrad_mfma_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw,
 }
 
 struct MfmaWgradPlan {
-    int CK, CIT, COB, TG, P, tilesD, tilesH, tilesW, ntiles;
+    int CK, CIT, COB, TG, P, tilesD, tilesH, tilesW, ntiles, v2;
     size_t part_floats, smem;
 };
 
@@ -695,6 +992,9 @@ static bool mfma_wgrad_plan(const Mri3dConvGeom& g, MfmaWgradPlan& p) {
     if (!(g.kd == 3 && g.kh == 3 && g.kw == 3 && g.sd == 1 && g.sh == 1 && g.sw == 1 && g.pd == 1 && g.ph == 1 &&
           g.pw == 1 && g.dd == 1 && g.dh == 1 && g.dw == 1))
         return false;
+    static const int use_v1 = getenv("MRI3D_WGRAD_V1") ? atoi(getenv("MRI3D_WGRAD_V1")) : 0;  // tuning aid (A/B)
+    // kernel version: 0 = v1 (any CK), 1 = v3 (CK = 8, register prefetch), 2 = v4 (CK = 16, small double-buffered tile)
+    p.v2 = (!use_v1 && g.ci % 8 == 0 && g.co % 4 == 0 && g.y_ld % 4 == 0) ? (g.ci % 16 == 0 ? 2 : 1) : 0;
     if (g.ci % 16 == 0) p.CK = 16;
     else if (g.ci % 8 == 0) p.CK = 8;
     else if (g.ci == 1) p.CK = 1;
@@ -704,7 +1004,7 @@ static bool mfma_wgrad_plan(const Mri3dConvGeom& g, MfmaWgradPlan& p) {
     p.COB = cdiv(g.co, 16);
     p.TG = wg_tap_groups(p.CK);
     p.tilesD = cdiv(g.di, WTD);
-    p.tilesH = cdiv(g.hi, WTH);
+    p.tilesH = cdiv(g.hi, p.v2 == 2 ? V4TH : WTH);
     p.tilesW = cdiv(g.wi, WTW);
     int64_t nt = (int64_t)g.n * p.tilesD * p.tilesH * p.tilesW;
     if (nt > 0x7fffffff) return false;
@@ -715,11 +1015,17 @@ static bool mfma_wgrad_plan(const Mri3dConvGeom& g, MfmaWgradPlan& p) {
     if (P < 1) P = 1;
     if (P > p.ntiles) P = p.ntiles;
     p.P = P;
-    p.part_floats = (size_t)P * pairs * (p.TG + 1) * 256;
+    p.part_floats = (size_t)P * p.CIT * p.COB * (p.TG + 1) * 256;
     size_t xs = ((size_t)WHVOX * p.CK + 3) & ~(size_t)3;
     size_t red = (size_t)(p.TG + 1) * 256;
     size_t tile_floats = xs + (size_t)WVOX * 16;
     p.smem = (tile_floats > red ? tile_floats : red) * sizeof(float);
+    if (p.v2 == 1) {
+        size_t xbuf = (size_t)((WHVOX * (p.CK / 4) + 255) / 256) * 256 * 4;
+        p.smem = std::max<size_t>(xbuf + (size_t)WVOX * 16, red) * sizeof(float);
+    } else if (p.v2 == 2) {
+        p.smem = std::max<size_t>((size_t)2 * V4XBUF + 2 * V4YBUF, red) * sizeof(float);
+    }
     return true;
 }
 
@@ -745,18 +1051,19 @@ template <int CK>
 static void launch_mfma_wgrad(const MfmaWgradPlan& p, const Mri3dConvGeom& g, const float* x, const float* dy,
                               float* part, bool bias, hipStream_t s) {
     dim3 grid(p.P, p.CIT, p.COB);
+    static const int ablate = getenv("MRI3D_ABLATE_W") ? atoi(getenv("MRI3D_ABLATE_W")) : 0;  // tuning aid
     if (bias) {
         auto kern = conv_mfma_wgrad_kernel<CK, true>;
         if (p.smem > 64 * 1024)
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.smem);
         hipLaunchKernelGGL(kern, grid, dim3(256), p.smem, s, x, dy, part, g.n, g.di, g.hi, g.wi, g.ci, g.x_ld, g.co,
-                           g.y_ld, p.tilesD, p.tilesH, p.tilesW, p.ntiles);
+                           g.y_ld, p.tilesD, p.tilesH, p.tilesW, p.ntiles, ablate);
     } else {
         auto kern = conv_mfma_wgrad_kernel<CK, false>;
         if (p.smem > 64 * 1024)
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.smem);
         hipLaunchKernelGGL(kern, grid, dim3(256), p.smem, s, x, dy, part, g.n, g.di, g.hi, g.wi, g.ci, g.x_ld, g.co,
-                           g.y_ld, p.tilesD, p.tilesH, p.tilesW, p.ntiles);
+                           g.y_ld, p.tilesD, p.tilesH, p.tilesW, p.ntiles, ablate);
     }
 }
 
@@ -772,7 +1079,32 @@ int conv_mfma_wgrad(const Mri3dConvGeom& g, const float* x, const float* dy, flo
     const bool bias = dbias != nullptr;
     // the kernel template always reserves the bias accumulator slot in the partial layout (TGA = TG + 1) only when BIAS;
     // keep the layout uniform by always running the BIAS variant when dbias is requested.
-    if (p.CK == 16) launch_mfma_wgrad<16>(p, g, x, dy, part, bias, s);
+    if (p.v2 == 2) {
+        dim3 grid(p.P, p.CIT, p.COB);
+#define MRI3D_WG4(Bv)                                                                                                 \
+    {                                                                                                                 \
+        auto kern = conv_mfma_wgrad4_kernel<Bv>;                                                                      \
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,   \
+                                  (int)p.smem);                                                                       \
+        hipLaunchKernelGGL(kern, grid, dim3(256), p.smem, s, x, dy, part, g.n, g.di, g.hi, g.wi, g.ci, g.x_ld, g.co,  \
+                           g.y_ld, p.tilesD, p.tilesH, p.tilesW, p.ntiles);                                           \
+    }
+        if (bias) MRI3D_WG4(true) else MRI3D_WG4(false)
+#undef MRI3D_WG4
+    } else if (p.v2 == 1) {
+        dim3 grid(p.P, p.CIT, p.COB);
+#define MRI3D_WG3(CKv, Bv)                                                                                            \
+    {                                                                                                                 \
+        auto kern = conv_mfma_wgrad3_kernel<CKv, Bv>;                                                                 \
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,   \
+                                  (int)p.smem);                                                                       \
+        hipLaunchKernelGGL(kern, grid, dim3(256), p.smem, s, x, dy, part, g.n, g.di, g.hi, g.wi, g.ci, g.x_ld, g.co,  \
+                           g.y_ld, p.tilesD, p.tilesH, p.tilesW, p.ntiles);                                           \
+    }
+        if (bias) MRI3D_WG3(8, true)
+        else MRI3D_WG3(8, false)
+#undef MRI3D_WG3
+    } else if (p.CK == 16) launch_mfma_wgrad<16>(p, g, x, dy, part, bias, s);
     else if (p.CK == 8) launch_mfma_wgrad<8>(p, g, x, dy, part, bias, s);
     else launch_mfma_wgrad<1>(p, g, x, dy, part, bias, s);
     const int TGA = p.TG + (bias ? 1 : 0);

@@ -148,7 +148,7 @@ def test_unet_flat_adam_data_parallel_step_matches_torch_adamw():
         oa.zero_grad(); ops.softmax_dice_loss(a(x), t).backward(); oa.step()
         ob.zero_grad(); ops.softmax_dice_loss(b(x), t).backward(); ob.step(fp.all_reduce())
     for pa, pb in zip(a.parameters(), b.parameters()):
-        assert_close(pb, pa, rel=1e-4)
+        assert_close(pb, pa, rel=2e-3)
 
 
 # ------------------------------------------------------------------------------------------------ classification
