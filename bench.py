@@ -146,8 +146,19 @@ def main():
             achieved, peak, unit, bound = work["flops"] / avg_s / 1e12, PEAK_F32_TFLOPS, "TFLOP/s", "mfma"
         else:
             achieved, peak, unit, bound = work["bytes"] / avg_s / 1e9, PEAK_HBM_GBS, "GB/s", "hbm"
+        # HBM traffic per launch of the dominant kernel: PMC counters cannot be read from inside this process, so the figure
+        # comes from the committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of the same kernel on the same
+        # geometry (profiles/r01_hbm_traffic_48_16.json, collected by tools/collect_traffic.py); null if not collected.
+        traffic = None
+        try:
+            with open(os.path.join(ROOT, "profiles", "r01_hbm_traffic_48_16.json")) as f:
+                rec = json.load(f).get(dom_tag)
+            if rec:
+                traffic = round(rec["traffic_bytes"])
+        except (OSError, ValueError):
+            pass
         roofline = {"bound": bound, "achieved": round(achieved, 3), "peak": peak, "unit": unit,
-                    "frac": round(achieved / peak, 4), "traffic": None, "kernel": dom_tag,
+                    "frac": round(achieved / peak, 4), "traffic": traffic, "kernel": dom_tag,
                     "avg_launch_ms": round(avg_s * 1e3, 4), "share_of_timed_ops": round(dom["ms"] / total_ms, 4)}
         top = sorted(agg.items(), key=lambda kv: -kv[1]["ms"])[:int(os.environ.get("MRI3D_BENCH_TOP", "12"))]
         sys.stderr.write("per-operator device time over %d steps (events on the launch stream):\n" % args.steps)

@@ -93,8 +93,7 @@ extern "C" int mri3d_conv3d_dgrad(const Mri3dConvGeom* g, const void* dy, const 
     if (rc) return rc;
     MRI3D_REQUIRE(dy && w && dx, MRI3D_EINVAL, "conv3d_dgrad: null pointer");
     hipStream_t s = static_cast<hipStream_t>(stream);
-    if (conv_pointwise_supported(*g, MRI3D_PASS_DGRAD) && (reinterpret_cast<uintptr_t>(dx) & 15) == 0 &&
-        (reinterpret_cast<uintptr_t>(w) & 15) == 0 && (reinterpret_cast<uintptr_t>(bias) & 15) == 0)
+    if (conv_pointwise_supported(*g, MRI3D_PASS_DGRAD) && (reinterpret_cast<uintptr_t>(dx) & 15) == 0)
         return conv_pointwise_dgrad(*g, (const float*)dy, (const float*)w, (const float*)bias, (float*)dx, s);
     if (conv_mfma_supported(*g, MRI3D_PASS_DGRAD))
         return conv_mfma_dgrad(*g, (const float*)dy, (const float*)w, (const float*)bias, (float*)dx, workspace, ws_bytes, s);

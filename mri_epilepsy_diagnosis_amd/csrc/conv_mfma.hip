@@ -224,9 +224,16 @@ conv_mfma_fwd2_kernel(const float* __restrict__ x, const float* __restrict__ wp,
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int li = lane & 15, kq = lane >> 4;
     const int nchunks = Kc / CK;
-    const int t_lo = (int)(((int64_t)ntiles * blockIdx.x) / gridDim.x);
-    const int t_hi = (int)(((int64_t)ntiles * (blockIdx.x + 1)) / gridDim.x);
-    const int nitems = (t_hi - t_lo) * nchunks;
+    // Tile -> workgroup map (speed only): blocks b and b+8 share an XCD (round-robin dispatch), so XCD k = b & 7 owns the
+    // contiguous tile range [ntiles*k/8, ntiles*(k+1)/8) and its workgroups take those tiles round-robin: at any moment
+    // the ~64 workgroups of an XCD work on ~64 CONSECUTIVE tiles, whose shared halo voxels then hit that XCD's L2
+    // instead of being re-fetched over the fabric.
+    const int NX = gridDim.x < 8 ? (int)gridDim.x : 8;                  // XCD groups that actually received a block
+    const int xcd = blockIdx.x % NX, wslot = blockIdx.x / NX;
+    const int wper = ((int)gridDim.x - xcd + NX - 1) / NX;             // workgroups living on this XCD
+    const int r_lo = (int)(((int64_t)ntiles * xcd) / NX), r_hi = (int)(((int64_t)ntiles * (xcd + 1)) / NX);
+    const int my_tiles = (r_hi - r_lo - wslot + wper - 1) / wper;      // tiles r_lo + wslot + k * wper < r_hi
+    const int nitems = (r_lo + wslot < r_hi ? my_tiles : 0) * nchunks;
     if (nitems <= 0) return;
 
     // per-lane staging geometry (independent of the item): piece j covers halo voxel (j*256+tid)>>1, channel quad &1
@@ -243,7 +250,7 @@ conv_mfma_fwd2_kernel(const float* __restrict__ x, const float* __restrict__ wp,
     struct Item { int n, d0, h0, w0, nt0, ch; };
     auto decode = [&](int it) -> Item {
         Item r;
-        int tile = t_lo + it / nchunks;
+        int tile = r_lo + wslot + (it / nchunks) * wper;
         r.ch = it % nchunks;
         r.nt0 = (tile % gy) * NT;
         tile /= gy;
@@ -653,6 +660,24 @@ conv_mfma_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ dy
     for (int i = tid; i < TGA * 256; i += 256) out[i] = red[i];
 }
 
+// Tile -> persistent-workgroup map shared by the wgrad kernels (speed only; see conv_mfma_fwd2_kernel): workgroups that
+// land on the same XCD (linear block id mod 8) take CONSECUTIVE tiles of that XCD's contiguous tile range round-robin.
+struct TileWalk { int first, stride, count; };
+__device__ __forceinline__ TileWalk tile_walk(int ntiles) {
+    const int P = gridDim.x;
+    const int NX = P < 8 ? P : 8;
+    const int off = (int)(((int64_t)P * (blockIdx.y + gridDim.y * blockIdx.z)) % NX);
+    const int grp = ((int)blockIdx.x + off) % NX;
+    const int p0 = (grp - off + NX) % NX;                 // first blockIdx.x of this XCD group in this (y, z) row
+    const int slot = ((int)blockIdx.x - p0) / NX, members = (P - p0 + NX - 1) / NX;
+    const int r_lo = (int)(((int64_t)ntiles * grp) / NX), r_hi = (int)(((int64_t)ntiles * (grp + 1)) / NX);
+    TileWalk w;
+    w.first = r_lo + slot;
+    w.stride = members;
+    w.count = w.first < r_hi ? (r_hi - w.first + members - 1) / members : 0;
+    return w;
+}
+
 // ------------------------------------------------------------------ weight gradient, version 3 (CK = 16 or 8)
 // v1 spends 2.3 of 5.1 ms of the 48->16 layer staging tiles while no MFMA runs (ablation: compute-only 130 TFLOP/s);
 // the two resident workgroups of a CU run in lock-step, so nothing hides it.  v3 keeps v1's compute (all tap-group
@@ -748,15 +773,14 @@ conv_mfma_wgrad3_kernel(const float* __restrict__ x, const float* __restrict__ d
         }
     };
 
-    const int P = gridDim.x;
-    const int t_lo = (int)(((int64_t)ntiles * blockIdx.x) / P), t_hi = (int)(((int64_t)ntiles * (blockIdx.x + 1)) / P);
-    if (t_hi > t_lo) {
-        load_tile(decode(t_lo));
+    const TileWalk tw = tile_walk(ntiles);
+    if (tw.count > 0) {
+        load_tile(decode(tw.first));
         store_tile();
         __syncthreads();
-        for (int tile = t_lo; tile < t_hi; ++tile) {
-            const bool has_next = tile + 1 < t_hi;
-            if (has_next) load_tile(decode(tile + 1));   // global -> registers, in flight during the MFMAs below
+        for (int k = 0; k < tw.count; ++k) {
+            const bool has_next = k + 1 < tw.count;
+            if (has_next) load_tile(decode(tw.first + (k + 1) * tw.stride));   // global -> registers, in flight during the MFMAs
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll 1
             for (int hr = 0; hr < 4; ++hr) {
@@ -892,7 +916,8 @@ conv_mfma_wgrad4_kernel(const float* __restrict__ x, const float* __restrict__ d
     auto row = [&](const float* xb, const float* yb, int hr) {
         const int hy = hsel * 2 + hr;
         // a REAL loop over the 4 k-steps (one basic block each): unrolled, hipcc hoists all four k-steps' LDS reads
-        // (108 VGPRs) on top of the 112 accumulators + 36 staging registers and spills (78 vs 96 TFLOP/s measured)
+        // (108 VGPRs) on top of the 112 accumulators + 36 staging registers and spills (78 vs 96 TFLOP/s measured); a
+        // ping-pong prefetch of the next k-step's fragments (2 x 28 VGPRs) spills as well.
 #pragma unroll 1
         for (int ks = 0; ks < 4; ++ks) {
             const int wx = ks * 4 + kq;
@@ -907,18 +932,17 @@ conv_mfma_wgrad4_kernel(const float* __restrict__ x, const float* __restrict__ d
         }
     };
 
-    const int P = gridDim.x;
-    const int t_lo = (int)(((int64_t)ntiles * blockIdx.x) / P), t_hi = (int)(((int64_t)ntiles * (blockIdx.x + 1)) / P);
-    if (t_hi > t_lo) {
-        load_tile(decode(t_lo));
+    const TileWalk tw = tile_walk(ntiles);
+    if (tw.count > 0) {
+        load_tile(decode(tw.first));
         store_tile(xs, dys);
         __syncthreads();
-        for (int tile = t_lo; tile < t_hi; ++tile) {
-            const int cb = (tile - t_lo) & 1;
+        for (int k = 0; k < tw.count; ++k) {
+            const int cb = k & 1;
             const float* xb = xs + cb * V4XBUF;
             const float* yb = dys + cb * V4YBUF;
-            const bool has_next = tile + 1 < t_hi;
-            if (has_next) load_tile(decode(tile + 1));        // global -> registers
+            const bool has_next = k + 1 < tw.count;
+            if (has_next) load_tile(decode(tw.first + (k + 1) * tw.stride));        // global -> registers
             __builtin_amdgcn_sched_barrier(0);
             row(xb, yb, 0);                                   // 108 MFMAs per wave cover the loads
             if (has_next) store_tile(xs + (cb ^ 1) * V4XBUF, dys + (cb ^ 1) * V4YBUF);  // registers -> the OTHER buffer

@@ -10,25 +10,46 @@
 
 namespace mri3d {
 
+// CO = compile-time bound on Co (weights of the lane's channel quad live in registers); QC = Ci/4 must divide 256 so
+// that a lane's quad never changes across the grid-stride loop; 4 independent voxels per iteration keep loads in flight.
+template <int CO>
 __global__ void __launch_bounds__(256)
 pw_dgrad_kernel(const float* __restrict__ dy, const float* __restrict__ w, const float* __restrict__ bias,
                 float* __restrict__ dx, int64_t nvox, int Ci, int Co, int x_ld, int y_ld) {
     const int QC = Ci >> 2;
-    const int64_t total = nvox * QC;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-        const int q = (int)(i % QC);
-        const int64_t v = i / QC;
-        float4 acc = bias ? *reinterpret_cast<const float4*>(bias + 4 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
-        const float* g = dy + v * y_ld;
-        for (int co = 0; co < Co; ++co) {
-            const float gv = g[co];
-            const float4 wv = *reinterpret_cast<const float4*>(w + (size_t)co * Ci + 4 * q);
-            acc.x = fmaf(gv, wv.x, acc.x);
-            acc.y = fmaf(gv, wv.y, acc.y);
-            acc.z = fmaf(gv, wv.z, acc.z);
-            acc.w = fmaf(gv, wv.w, acc.w);
+    const int q = threadIdx.x % QC, vl = threadIdx.x / QC, VL = 256 / QC;
+    float4 wq[CO];
+#pragma unroll
+    for (int co = 0; co < CO; ++co) {   // scalar loads: parameters may be views into a flat buffer (only 4-byte aligned)
+        const float* wr = w + (size_t)(co < Co ? co : 0) * Ci + 4 * q;
+        wq[co] = co < Co ? make_float4(wr[0], wr[1], wr[2], wr[3]) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    const float4 b4 = bias ? make_float4(bias[4 * q], bias[4 * q + 1], bias[4 * q + 2], bias[4 * q + 3])
+                           : make_float4(0.f, 0.f, 0.f, 0.f);
+    constexpr int U = 4;
+    const int64_t stride = (int64_t)gridDim.x * VL;
+    for (int64_t v0 = (int64_t)blockIdx.x * VL + vl; v0 < nvox; v0 += stride * U) {
+        float gv[U][CO];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int64_t v = v0 + u * stride;
+#pragma unroll
+            for (int co = 0; co < CO; ++co) gv[u][co] = (v < nvox && co < Co) ? dy[v * y_ld + co] : 0.f;
         }
-        *reinterpret_cast<float4*>(dx + v * x_ld + 4 * q) = acc;
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int64_t v = v0 + u * stride;
+            if (v >= nvox) break;
+            float4 acc = b4;
+#pragma unroll
+            for (int co = 0; co < CO; ++co) {
+                acc.x = fmaf(gv[u][co], wq[co].x, acc.x);
+                acc.y = fmaf(gv[u][co], wq[co].y, acc.y);
+                acc.z = fmaf(gv[u][co], wq[co].z, acc.z);
+                acc.w = fmaf(gv[u][co], wq[co].w, acc.w);
+            }
+            *reinterpret_cast<float4*>(dx + v * x_ld + 4 * q) = acc;
+        }
     }
 }
 
@@ -52,17 +73,29 @@ pw_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ dy, doubl
         for (int a = 0; a < 4; ++a) acc[a][c] = 0.0;
     }
     if (vl < VL) {
-        for (int64_t v = (int64_t)blockIdx.x * VL + vl; v < nvox; v += (int64_t)gridDim.x * VL) {
-            const float4 xv = *reinterpret_cast<const float4*>(x + v * x_ld + 4 * q);
-            const float* g = dy + v * y_ld;
+        constexpr int U = 4;
+        const int64_t stride = (int64_t)gridDim.x * VL;
+        for (int64_t v0 = (int64_t)blockIdx.x * VL + vl; v0 < nvox; v0 += stride * U) {
+            float4 xv[U];
+            float gv[U][CO];
 #pragma unroll
-            for (int c = 0; c < CO; ++c) {
-                const float gv = c < Co ? g[c] : 0.f;
-                acc[0][c] += (double)(xv.x * gv);
-                acc[1][c] += (double)(xv.y * gv);
-                acc[2][c] += (double)(xv.z * gv);
-                acc[3][c] += (double)(xv.w * gv);
-                if (q == 0) bsum[c] += (double)gv;
+            for (int u = 0; u < U; ++u) {   // issue all loads of the 4 voxels first
+                const int64_t v = v0 + u * stride;
+                const bool ok = v < nvox;
+                xv[u] = ok ? *reinterpret_cast<const float4*>(x + v * x_ld + 4 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+                for (int c = 0; c < CO; ++c) gv[u][c] = (ok && c < Co) ? dy[v * y_ld + c] : 0.f;
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+#pragma unroll
+                for (int c = 0; c < CO; ++c) {
+                    acc[0][c] += (double)(xv[u].x * gv[u][c]);
+                    acc[1][c] += (double)(xv[u].y * gv[u][c]);
+                    acc[2][c] += (double)(xv[u].z * gv[u][c]);
+                    acc[3][c] += (double)(xv[u].w * gv[u][c]);
+                    if (q == 0) bsum[c] += (double)gv[u][c];
+                }
             }
         }
     }
@@ -88,18 +121,26 @@ pw_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ dy, doubl
     }
 }
 
-__global__ void pw_wgrad_reduce_kernel(const double* __restrict__ part, const double* __restrict__ bias_part,
-                                       float* __restrict__ dw, float* __restrict__ dbias, int nb, int Ci, int Co) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < Co * Ci) {
-        double s = 0.0;
-        for (int b = 0; b < nb; ++b) s += part[(size_t)b * Co * Ci + i];
-        dw[i] = (float)s;
-    }
-    if (dbias != nullptr && i < Co) {
-        double s = 0.0;
-        for (int b = 0; b < nb; ++b) s += bias_part[(size_t)b * Co + i];
-        dbias[i] = (float)s;
+// one block per output element group: 256 threads = 8 elements x 32 partial lanes, fixed-order combine in double
+__global__ void __launch_bounds__(256)
+pw_wgrad_reduce_kernel(const double* __restrict__ part, const double* __restrict__ bias_part, float* __restrict__ dw,
+                       float* __restrict__ dbias, int nb, int Ci, int Co) {
+    __shared__ double red[256];
+    const int el = threadIdx.x >> 5, ql = threadIdx.x & 31;
+    const int nw = Co * Ci, ntot = nw + (dbias != nullptr ? Co : 0);
+    const int i = blockIdx.x * 8 + el;
+    double s = 0.0;
+    if (i < nw)
+        for (int b = ql; b < nb; b += 32) s += part[(size_t)b * nw + i];
+    else if (i < ntot)
+        for (int b = ql; b < nb; b += 32) s += bias_part[(size_t)b * Co + (i - nw)];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    if (ql == 0 && i < ntot) {
+        double t = 0.0;
+        for (int k = 0; k < 32; ++k) t += red[el * 32 + k];
+        if (i < nw) dw[i] = (float)t;
+        else dbias[i - nw] = (float)t;
     }
 }
 
@@ -117,7 +158,7 @@ static int pw_blocks(const Mri3dConvGeom& g) {
 
 bool conv_pointwise_supported(const Mri3dConvGeom& g, int pass) {
     if (!is_pointwise(g) || g.ci % 4 != 0 || g.x_ld % 4 != 0 || g.ci > 256) return false;
-    if (pass == MRI3D_PASS_DGRAD) return g.co <= 16;
+    if (pass == MRI3D_PASS_DGRAD) return g.co <= 8 && 256 % (g.ci >> 2) == 0;
     if (pass == MRI3D_PASS_WGRAD) return g.co <= 8 && g.ci <= 64;
     return false;
 }
@@ -129,11 +170,17 @@ size_t conv_pointwise_workspace_bytes(const Mri3dConvGeom& g, int pass) {
 
 int conv_pointwise_dgrad(const Mri3dConvGeom& g, const float* dy, const float* w, const float* bias, float* dx,
                          hipStream_t s) {
-    MRI3D_REQUIRE(((reinterpret_cast<uintptr_t>(dx) | reinterpret_cast<uintptr_t>(w) | reinterpret_cast<uintptr_t>(bias)) & 15) == 0,
-                  MRI3D_EINVAL, "conv3d_dgrad(pointwise): dx/w/bias must be 16-byte aligned");
+    MRI3D_REQUIRE((reinterpret_cast<uintptr_t>(dx) & 15) == 0, MRI3D_EINVAL,
+                  "conv3d_dgrad(pointwise): dx must be 16-byte aligned");
     const int64_t nvox = (int64_t)g.n * g.di * g.hi * g.wi;
-    hipLaunchKernelGGL(pw_dgrad_kernel, dim3(stream_grid(nvox * (g.ci >> 2), 256)), dim3(256), 0, s, dy, w, bias, dx, nvox,
-                       g.ci, g.co, g.x_ld, g.y_ld);
+    const int VL = 256 / (g.ci >> 2);
+    const unsigned grid = (unsigned)std::max<int64_t>(1, std::min<int64_t>(cdiv64(nvox, (int64_t)VL * 4), 2048));
+    if (g.co <= 2)
+        hipLaunchKernelGGL(pw_dgrad_kernel<2>, dim3(grid), dim3(256), 0, s, dy, w, bias, dx, nvox, g.ci, g.co, g.x_ld, g.y_ld);
+    else if (g.co <= 4)
+        hipLaunchKernelGGL(pw_dgrad_kernel<4>, dim3(grid), dim3(256), 0, s, dy, w, bias, dx, nvox, g.ci, g.co, g.x_ld, g.y_ld);
+    else
+        hipLaunchKernelGGL(pw_dgrad_kernel<8>, dim3(grid), dim3(256), 0, s, dy, w, bias, dx, nvox, g.ci, g.co, g.x_ld, g.y_ld);
     return check_launch("conv3d_dgrad(pointwise)");
 }
 
@@ -157,8 +204,8 @@ int conv_pointwise_wgrad(const Mri3dConvGeom& g, const float* x, const float* dy
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(pw_wgrad_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         hipLaunchKernelGGL(pw_wgrad_kernel<8>, dim3(nb), dim3(256), smem, s, x, dy, part, bias_part, nvox, g.ci, g.co, g.x_ld, g.y_ld);
     }
-    hipLaunchKernelGGL(pw_wgrad_reduce_kernel, dim3(cdiv(g.co * g.ci, 256)), dim3(256), 0, s, part, bias_part, dw, dbias, nb,
-                       g.ci, g.co);
+    hipLaunchKernelGGL(pw_wgrad_reduce_kernel, dim3(cdiv(g.co * g.ci + g.co, 8)), dim3(256), 0, s, part, bias_part, dw, dbias,
+                       nb, g.ci, g.co);
     return check_launch("conv3d_wgrad(pointwise)");
 }
 

@@ -67,34 +67,45 @@ dice_fwd_kernel(const float* __restrict__ logits, const float* __restrict__ targ
     }
 }
 
-// one block: stats[n][c][3] and the scalar loss
-__global__ void dice_finalize_kernel(const double* __restrict__ part, float* __restrict__ stats, float* __restrict__ loss,
-                                     int N, int C, int nblk, float eps) {
-    __shared__ double acc[256];
-    double my = 0.0;
-    for (int i = threadIdx.x; i < N * C; i += blockDim.x) {
-        int n = i / C, c = i - n * C;
-        double tp = 0.0, sp = 0.0, sg = 0.0;
-        const double* p = part + ((size_t)n * nblk * C + c) * 3;
-        for (int q = 0; q < nblk; ++q) {
-            tp += p[(size_t)q * C * 3];
-            sp += p[(size_t)q * C * 3 + 1];
-            sg += p[(size_t)q * C * 3 + 2];
-        }
-        stats[i * 3] = (float)tp;
-        stats[i * 3 + 1] = (float)sp;
-        stats[i * 3 + 2] = (float)sg;
-        // float arithmetic from here mirrors the reference's fp32 tensors
-        float ftp = (float)tp, den = 2.f * ftp + ((float)sp - ftp) + ((float)sg - ftp) + eps;
-        my += 1.0 - (double)(2.f * ftp / den);
-    }
-    acc[threadIdx.x] = my;
+// one block of 256 threads: (n, c) pairs are handled 8 at a time by 32 partial lanes each (fixed-order double sums)
+__global__ void __launch_bounds__(256)
+dice_finalize_kernel(const double* __restrict__ part, float* __restrict__ stats, float* __restrict__ loss, int N, int C,
+                     int nblk, float eps) {
+    __shared__ double r0[256], r1[256], r2[256];
+    __shared__ double acc_loss;
+    const int el = threadIdx.x >> 5, ql = threadIdx.x & 31;
+    if (threadIdx.x == 0) acc_loss = 0.0;
     __syncthreads();
-    if (threadIdx.x == 0) {
-        double t = 0.0;
-        for (int i = 0; i < (int)blockDim.x; ++i) t += acc[i];
-        loss[0] = (float)(t / (double)(N * C));
+    for (int base = 0; base < N * C; base += 8) {
+        const int i = base + el;
+        double tp = 0.0, sp = 0.0, sg = 0.0;
+        if (i < N * C) {
+            const int n = i / C, c = i - n * C;
+            const double* p = part + ((size_t)n * nblk * C + c) * 3;
+            for (int q = ql; q < nblk; q += 32) {
+                tp += p[(size_t)q * C * 3];
+                sp += p[(size_t)q * C * 3 + 1];
+                sg += p[(size_t)q * C * 3 + 2];
+            }
+        }
+        r0[threadIdx.x] = tp; r1[threadIdx.x] = sp; r2[threadIdx.x] = sg;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            for (int e = 0; e < 8 && base + e < N * C; ++e) {
+                double a = 0.0, b = 0.0, d = 0.0;
+                for (int k = 0; k < 32; ++k) { a += r0[e * 32 + k]; b += r1[e * 32 + k]; d += r2[e * 32 + k]; }
+                const int i2 = base + e;
+                stats[i2 * 3] = (float)a;
+                stats[i2 * 3 + 1] = (float)b;
+                stats[i2 * 3 + 2] = (float)d;
+                // float arithmetic from here mirrors the reference's fp32 tensors
+                const float ftp = (float)a, den = 2.f * ftp + ((float)b - ftp) + ((float)d - ftp) + eps;
+                acc_loss += 1.0 - (double)(2.f * ftp / den);
+            }
+        }
+        __syncthreads();
     }
+    if (threadIdx.x == 0) loss[0] = (float)(acc_loss / (double)(N * C));
 }
 
 template <int C>

@@ -8,6 +8,7 @@
 // are written as gathers (each destination element is produced by exactly one thread) => deterministic, no atomics.
 #include "common.h"
 #include <limits.h>
+#include <algorithm>
 
 namespace mri3d {
 
@@ -28,60 +29,68 @@ struct V {
     }
 };
 
+// Indexing scheme of every kernel in this file: a block walks (n, depth) slabs (scalar decode, 64-bit safe) and its
+// threads walk the (h, w, channel-vector) elements of the slab with 32-bit arithmetic — 64-bit divisions per element
+// made the first version of these kernels VALU-bound at 1.3-2.2 TB/s.
+
 // ------------------------------------------------------------------ max pool forward
 template <int VEC>
 __global__ void __launch_bounds__(256)
-maxpool_fwd_kernel(Mri3dPoolGeom g, const float* __restrict__ x, float* __restrict__ y, uint8_t* __restrict__ idx) {
-    const int CV = g.c / VEC;
-    const int64_t total = (int64_t)g.n * g.dout * g.ho * g.wo * CV;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-        int cv = (int)(i % CV);
-        int64_t ov = i / CV;
-        int ow = (int)(ov % g.wo);
-        int64_t t = ov / g.wo;
-        int oh = (int)(t % g.ho);
-        t /= g.ho;
-        int od = (int)(t % g.dout);
-        int n = (int)(t / g.dout);
-        float best[VEC];
-        int bi[VEC];
+maxpool_fwd_kernel(Mri3dPoolGeom g, const float* __restrict__ x, float* __restrict__ y, uint8_t* __restrict__ idx, int hch) {
+    const unsigned CV = g.c / VEC;
+    const int hchunks = (g.ho + hch - 1) / hch;
+    const int slabs = g.n * g.dout * hchunks;
+    for (int slab = blockIdx.x; slab < slabs; slab += gridDim.x) {
+        const int hc = slab % hchunks, nd = slab / hchunks;
+        const int n = nd / g.dout, od = nd - n * g.dout;
+        const int h0 = hc * hch, hn = min(hch, g.ho - h0);
+        const unsigned inner = (unsigned)hn * g.wo * CV;
+        const float* xn = x + (int64_t)n * g.di * g.hi * g.wi * g.x_ld;
+        const int64_t obase = ((int64_t)nd * g.ho + h0) * g.wo;
+        for (unsigned e = threadIdx.x; e < inner; e += blockDim.x) {
+            const unsigned cv = e % CV, pix = e / CV;
+            const int ow = pix % g.wo, oh = h0 + pix / g.wo;
+            float best[VEC];
+            int bi[VEC];
 #pragma unroll
-        for (int j = 0; j < VEC; ++j) { best[j] = -INFINITY; bi[j] = 0; }
-        bool first = true;
-        for (int kd = 0; kd < g.kd; ++kd) {
-            int id = od * g.sd - g.pd + kd;
-            if ((unsigned)id >= (unsigned)g.di) continue;
-            for (int kh = 0; kh < g.kh; ++kh) {
-                int ih = oh * g.sh - g.ph + kh;
-                if ((unsigned)ih >= (unsigned)g.hi) continue;
-                for (int kw = 0; kw < g.kw; ++kw) {
-                    int iw = ow * g.sw - g.pw + kw;
-                    if ((unsigned)iw >= (unsigned)g.wi) continue;
-                    V<VEC> xv;
-                    xv.load(x + ((((int64_t)n * g.di + id) * g.hi + ih) * g.wi + iw) * g.x_ld + cv * VEC);
-                    int tap = (kd * g.kh + kh) * g.kw + kw;
+            for (int j = 0; j < VEC; ++j) { best[j] = -INFINITY; bi[j] = 0; }
+            bool first = true;
+            for (int kd = 0; kd < g.kd; ++kd) {
+                const int id = od * g.sd - g.pd + kd;
+                if ((unsigned)id >= (unsigned)g.di) continue;
+                for (int kh = 0; kh < g.kh; ++kh) {
+                    const int ih = oh * g.sh - g.ph + kh;
+                    if ((unsigned)ih >= (unsigned)g.hi) continue;
+                    for (int kw = 0; kw < g.kw; ++kw) {
+                        const int iw = ow * g.sw - g.pw + kw;
+                        if ((unsigned)iw >= (unsigned)g.wi) continue;
+                        V<VEC> xv;
+                        xv.load(xn + (((int64_t)id * g.hi + ih) * g.wi + iw) * g.x_ld + cv * VEC);
+                        const int tap = (kd * g.kh + kh) * g.kw + kw;
 #pragma unroll
-                    for (int j = 0; j < VEC; ++j) {
-                        // torch: first maximum in raster order wins; NaN propagates
-                        if (first || xv.v[j] > best[j] || xv.v[j] != xv.v[j]) {
-                            best[j] = xv.v[j];
-                            bi[j] = tap;
+                        for (int j = 0; j < VEC; ++j) {
+                            // torch: first maximum in raster order wins; NaN propagates
+                            if (first || xv.v[j] > best[j] || xv.v[j] != xv.v[j]) {
+                                best[j] = xv.v[j];
+                                bi[j] = tap;
+                            }
                         }
+                        first = false;
                     }
-                    first = false;
                 }
             }
-        }
-        V<VEC> o;
+            V<VEC> o;
 #pragma unroll
-        for (int j = 0; j < VEC; ++j) o.v[j] = best[j];
-        o.store(y + ov * g.y_ld + cv * VEC);
-        uint8_t* ip = idx + ov * g.c + cv * VEC;
-        if (VEC == 4) {
-            *reinterpret_cast<uint32_t*>(ip) = (uint32_t)bi[0] | ((uint32_t)bi[1] << 8) | ((uint32_t)bi[VEC > 2 ? 2 : 0] << 16) |
-                                               ((uint32_t)bi[VEC > 3 ? 3 : 0] << 24);
-        } else {
-            ip[0] = (uint8_t)bi[0];
+            for (int j = 0; j < VEC; ++j) o.v[j] = best[j];
+            const int64_t ov = obase + pix;
+            o.store(y + ov * g.y_ld + cv * VEC);
+            uint8_t* ip = idx + ov * g.c + cv * VEC;
+            if (VEC == 4) {
+                *reinterpret_cast<uint32_t*>(ip) = (uint32_t)bi[0] | ((uint32_t)bi[1] << 8) |
+                                                   ((uint32_t)bi[VEC > 2 ? 2 : 0] << 16) | ((uint32_t)bi[VEC > 3 ? 3 : 0] << 24);
+            } else {
+                ip[0] = (uint8_t)bi[0];
+            }
         }
     }
 }
@@ -90,54 +99,56 @@ maxpool_fwd_kernel(Mri3dPoolGeom g, const float* __restrict__ x, float* __restri
 template <int VEC>
 __global__ void __launch_bounds__(256)
 maxpool_bwd_kernel(Mri3dPoolGeom g, const float* __restrict__ dy, const uint8_t* __restrict__ idx,
-                   float* __restrict__ dx) {
-    const int CV = g.c / VEC;
-    const int64_t total = (int64_t)g.n * g.di * g.hi * g.wi * CV;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-        int cv = (int)(i % CV);
-        int64_t iv = i / CV;
-        int iw = (int)(iv % g.wi);
-        int64_t t = iv / g.wi;
-        int ih = (int)(t % g.hi);
-        t /= g.hi;
-        int id = (int)(t % g.di);
-        int n = (int)(t / g.di);
-        float acc[VEC];
-#pragma unroll
-        for (int j = 0; j < VEC; ++j) acc[j] = 0.f;
+                   float* __restrict__ dx, int hch) {
+    const unsigned CV = g.c / VEC;
+    const int hchunks = (g.hi + hch - 1) / hch;
+    const int slabs = g.n * g.di * hchunks;
+    for (int slab = blockIdx.x; slab < slabs; slab += gridDim.x) {
+        const int hc = slab % hchunks, nd = slab / hchunks;
+        const int n = nd / g.di, id = nd - n * g.di;
+        const int h0 = hc * hch, hn = min(hch, g.hi - h0);
+        const unsigned inner = (unsigned)hn * g.wi * CV;
         // windows od with od*sd - pd <= id <= od*sd - pd + kd - 1
         int od_lo = id + g.pd - g.kd + 1; od_lo = od_lo <= 0 ? 0 : (od_lo + g.sd - 1) / g.sd;
         int od_hi = (id + g.pd) / g.sd; if (od_hi > g.dout - 1) od_hi = g.dout - 1;
-        int oh_lo = ih + g.ph - g.kh + 1; oh_lo = oh_lo <= 0 ? 0 : (oh_lo + g.sh - 1) / g.sh;
-        int oh_hi = (ih + g.ph) / g.sh; if (oh_hi > g.ho - 1) oh_hi = g.ho - 1;
-        int ow_lo = iw + g.pw - g.kw + 1; ow_lo = ow_lo <= 0 ? 0 : (ow_lo + g.sw - 1) / g.sw;
-        int ow_hi = (iw + g.pw) / g.sw; if (ow_hi > g.wo - 1) ow_hi = g.wo - 1;
-        for (int od = od_lo; od <= od_hi; ++od) {
-            int kd = id - (od * g.sd - g.pd);
-            for (int oh = oh_lo; oh <= oh_hi; ++oh) {
-                int kh = ih - (oh * g.sh - g.ph);
-                for (int ow = ow_lo; ow <= ow_hi; ++ow) {
-                    int kw = iw - (ow * g.sw - g.pw);
-                    int tap = (kd * g.kh + kh) * g.kw + kw;
-                    int64_t ov = (((int64_t)n * g.dout + od) * g.ho + oh) * g.wo + ow;
-                    V<VEC> gv;
-                    gv.load(dy + ov * g.y_ld + cv * VEC);
-                    const uint8_t* ip = idx + ov * g.c + cv * VEC;
-                    if (VEC == 4) {
-                        uint32_t pk = *reinterpret_cast<const uint32_t*>(ip);
+        const int64_t ibase = ((int64_t)nd * g.hi + h0) * g.wi;
+        for (unsigned e = threadIdx.x; e < inner; e += blockDim.x) {
+            const unsigned cv = e % CV, pix = e / CV;
+            const int iw = pix % g.wi, ih = h0 + pix / g.wi;
+            float acc[VEC];
 #pragma unroll
-                        for (int j = 0; j < VEC; ++j)
-                            if ((int)((pk >> (8 * j)) & 0xff) == tap) acc[j] += gv.v[j];
-                    } else {
-                        if ((int)ip[0] == tap) acc[0] += gv.v[0];
+            for (int j = 0; j < VEC; ++j) acc[j] = 0.f;
+            int oh_lo = ih + g.ph - g.kh + 1; oh_lo = oh_lo <= 0 ? 0 : (oh_lo + g.sh - 1) / g.sh;
+            int oh_hi = (ih + g.ph) / g.sh; if (oh_hi > g.ho - 1) oh_hi = g.ho - 1;
+            int ow_lo = iw + g.pw - g.kw + 1; ow_lo = ow_lo <= 0 ? 0 : (ow_lo + g.sw - 1) / g.sw;
+            int ow_hi = (iw + g.pw) / g.sw; if (ow_hi > g.wo - 1) ow_hi = g.wo - 1;
+            for (int od = od_lo; od <= od_hi; ++od) {
+                const int kd = id - (od * g.sd - g.pd);
+                for (int oh = oh_lo; oh <= oh_hi; ++oh) {
+                    const int kh = ih - (oh * g.sh - g.ph);
+                    for (int ow = ow_lo; ow <= ow_hi; ++ow) {
+                        const int kw = iw - (ow * g.sw - g.pw);
+                        const int tap = (kd * g.kh + kh) * g.kw + kw;
+                        const int64_t ov = (((int64_t)n * g.dout + od) * g.ho + oh) * g.wo + ow;
+                        V<VEC> gv;
+                        gv.load(dy + ov * g.y_ld + cv * VEC);
+                        const uint8_t* ip = idx + ov * g.c + cv * VEC;
+                        if (VEC == 4) {
+                            const uint32_t pk = *reinterpret_cast<const uint32_t*>(ip);
+#pragma unroll
+                            for (int j = 0; j < VEC; ++j)
+                                if ((int)((pk >> (8 * j)) & 0xff) == tap) acc[j] += gv.v[j];
+                        } else {
+                            if ((int)ip[0] == tap) acc[0] += gv.v[0];
+                        }
                     }
                 }
             }
-        }
-        V<VEC> o;
+            V<VEC> o;
 #pragma unroll
-        for (int j = 0; j < VEC; ++j) o.v[j] = acc[j];
-        o.store(dx + iv * g.x_ld + cv * VEC);
+            for (int j = 0; j < VEC; ++j) o.v[j] = acc[j];
+            o.store(dx + (ibase + pix) * g.x_ld + cv * VEC);
+        }
     }
 }
 
@@ -164,50 +175,57 @@ __device__ __forceinline__ int near_src(int o, float r, int in_size) {
 
 template <int VEC>
 __global__ void __launch_bounds__(256)
-upsample_fwd_kernel(Mri3dUpGeom g, const float* __restrict__ x, float* __restrict__ y) {
-    const int CV = g.c / VEC;
-    const int64_t total = (int64_t)g.n * g.dout * g.ho * g.wo * CV;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-        int cv = (int)(i % CV);
-        int64_t ov = i / CV;
-        int ow = (int)(ov % g.wo);
-        int64_t t = ov / g.wo;
-        int oh = (int)(t % g.ho);
-        t /= g.ho;
-        int od = (int)(t % g.dout);
-        int n = (int)(t / g.dout);
-        const float* xn = x + (int64_t)n * g.di * g.hi * g.wi * g.x_ld + cv * VEC;
-        V<VEC> o;
-        if (g.mode == MRI3D_UP_NEAREST) {
-            int id = near_src(od, g.rd, g.di), ih = near_src(oh, g.rh, g.hi), iw = near_src(ow, g.rw, g.wi);
-            o.load(xn + (((int64_t)id * g.hi + ih) * g.wi + iw) * g.x_ld);
-        } else {
-            Lin Ld_ = lin_src(od, g.rd, g.di, g.align_corners);
-            Lin Lh = lin_src(oh, g.rh, g.hi, g.align_corners);
-            Lin Lw = lin_src(ow, g.rw, g.wi, g.align_corners);
+upsample_fwd_kernel(Mri3dUpGeom g, const float* __restrict__ x, float* __restrict__ y, int hch) {
+    const unsigned CV = g.c / VEC;
+    const int hchunks = (g.ho + hch - 1) / hch;
+    const int slabs = g.n * g.dout * hchunks;
+    for (int slab = blockIdx.x; slab < slabs; slab += gridDim.x) {
+        const int hc = slab % hchunks, nd = slab / hchunks;
+        const int n = nd / g.dout, od = nd - n * g.dout;
+        const int h0 = hc * hch, hn = min(hch, g.ho - h0);
+        const unsigned inner = (unsigned)hn * g.wo * CV;
+        const float* xn = x + (int64_t)n * g.di * g.hi * g.wi * g.x_ld;
+        const int64_t obase = ((int64_t)nd * g.ho + h0) * g.wo;
+        // depth taps are uniform over the slab
+        int idn = 0;
+        Lin Ld_ = {0, 0, 1.f, 0.f};
+        if (g.mode == MRI3D_UP_NEAREST) idn = near_src(od, g.rd, g.di);
+        else Ld_ = lin_src(od, g.rd, g.di, g.align_corners);
+        for (unsigned e = threadIdx.x; e < inner; e += blockDim.x) {
+            const unsigned cv = e % CV, pix = e / CV;
+            const int ow = pix % g.wo, oh = h0 + pix / g.wo;
+            const float* xc = xn + cv * VEC;
+            V<VEC> o;
+            if (g.mode == MRI3D_UP_NEAREST) {
+                const int ih = near_src(oh, g.rh, g.hi), iw = near_src(ow, g.rw, g.wi);
+                o.load(xc + (((int64_t)idn * g.hi + ih) * g.wi + iw) * g.x_ld);
+            } else {
+                const Lin Lh = lin_src(oh, g.rh, g.hi, g.align_corners);
+                const Lin Lw = lin_src(ow, g.rw, g.wi, g.align_corners);
 #pragma unroll
-            for (int j = 0; j < VEC; ++j) o.v[j] = 0.f;
+                for (int j = 0; j < VEC; ++j) o.v[j] = 0.f;
 #pragma unroll
-            for (int a = 0; a < 2; ++a) {
-                int id = a ? Ld_.i1 : Ld_.i0;
-                float wd = a ? Ld_.l1 : Ld_.l0;
+                for (int a = 0; a < 2; ++a) {
+                    const int id = a ? Ld_.i1 : Ld_.i0;
+                    const float wd = a ? Ld_.l1 : Ld_.l0;
 #pragma unroll
-                for (int b = 0; b < 2; ++b) {
-                    int ih = b ? Lh.i1 : Lh.i0;
-                    float wh = wd * (b ? Lh.l1 : Lh.l0);
+                    for (int b = 0; b < 2; ++b) {
+                        const int ih = b ? Lh.i1 : Lh.i0;
+                        const float wh = wd * (b ? Lh.l1 : Lh.l0);
 #pragma unroll
-                    for (int c = 0; c < 2; ++c) {
-                        int iw = c ? Lw.i1 : Lw.i0;
-                        float w = wh * (c ? Lw.l1 : Lw.l0);
-                        V<VEC> xv;
-                        xv.load(xn + (((int64_t)id * g.hi + ih) * g.wi + iw) * g.x_ld);
+                        for (int c = 0; c < 2; ++c) {
+                            const int iw = c ? Lw.i1 : Lw.i0;
+                            const float w = wh * (c ? Lw.l1 : Lw.l0);
+                            V<VEC> xv;
+                            xv.load(xc + (((int64_t)id * g.hi + ih) * g.wi + iw) * g.x_ld);
 #pragma unroll
-                        for (int j = 0; j < VEC; ++j) o.v[j] = fmaf(w, xv.v[j], o.v[j]);
+                            for (int j = 0; j < VEC; ++j) o.v[j] = fmaf(w, xv.v[j], o.v[j]);
+                        }
                     }
                 }
             }
+            o.store(y + (obase + pix) * g.y_ld + cv * VEC);
         }
-        o.store(y + ov * g.y_ld + cv * VEC);
     }
 }
 
@@ -245,47 +263,59 @@ __device__ __forceinline__ float up_weight(int o, int i, float r, int in_size, i
 
 template <int VEC>
 __global__ void __launch_bounds__(256)
-upsample_bwd_kernel(Mri3dUpGeom g, const float* __restrict__ dy, float* __restrict__ dx, const int* __restrict__ tab) {
-    const int CV = g.c / VEC;
+upsample_bwd_kernel(Mri3dUpGeom g, const float* __restrict__ dy, float* __restrict__ dx, const int* __restrict__ tab, int hch) {
+    const unsigned CV = g.c / VEC;
     const int* lo_d = tab; const int* hi_d = tab + g.di;
     const int* lo_h = tab + 2 * g.di; const int* hi_h = lo_h + g.hi;
     const int* lo_w = tab + 2 * g.di + 2 * g.hi; const int* hi_w = lo_w + g.wi;
-    const int64_t total = (int64_t)g.n * g.di * g.hi * g.wi * CV;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-        int cv = (int)(i % CV);
-        int64_t iv = i / CV;
-        int iw = (int)(iv % g.wi);
-        int64_t t = iv / g.wi;
-        int ih = (int)(t % g.hi);
-        t /= g.hi;
-        int id = (int)(t % g.di);
-        int n = (int)(t / g.di);
-        float acc[VEC];
+    const int hchunks = (g.hi + hch - 1) / hch;
+    const int slabs = g.n * g.di * hchunks;
+    for (int slab = blockIdx.x; slab < slabs; slab += gridDim.x) {
+        const int hc = slab % hchunks, nd = slab / hchunks;
+        const int n = nd / g.di, id = nd - n * g.di;
+        const int hh0 = hc * hch, hn = min(hch, g.hi - hh0);
+        const unsigned inner = (unsigned)hn * g.wi * CV;
+        const int d0 = lo_d[id], d1 = hi_d[id];
+        const float* dn = dy + (int64_t)n * g.dout * g.ho * g.wo * g.y_ld;
+        const int64_t ibase = ((int64_t)nd * g.hi + hh0) * g.wi;
+        for (unsigned e = threadIdx.x; e < inner; e += blockDim.x) {
+            const unsigned cv = e % CV, pix = e / CV;
+            const int iw = pix % g.wi, ih = hh0 + pix / g.wi;
+            float acc[VEC];
 #pragma unroll
-        for (int j = 0; j < VEC; ++j) acc[j] = 0.f;
-        const float* dn = dy + (int64_t)n * g.dout * g.ho * g.wo * g.y_ld + cv * VEC;
-        const int d0 = lo_d[id], d1 = hi_d[id], h0 = lo_h[ih], h1 = hi_h[ih], w0 = lo_w[iw], w1 = hi_w[iw];
-        for (int od = d0; od <= d1; ++od) {
-            float wd = up_weight(od, id, g.rd, g.di, g.mode, g.align_corners);
-            if (wd == 0.f) continue;
-            for (int oh = h0; oh <= h1; ++oh) {
-                float wh = wd * up_weight(oh, ih, g.rh, g.hi, g.mode, g.align_corners);
-                if (wh == 0.f) continue;
-                for (int ow = w0; ow <= w1; ++ow) {
-                    float w = wh * up_weight(ow, iw, g.rw, g.wi, g.mode, g.align_corners);
-                    if (w == 0.f) continue;
-                    V<VEC> gv;
-                    gv.load(dn + (((int64_t)od * g.ho + oh) * g.wo + ow) * g.y_ld);
+            for (int j = 0; j < VEC; ++j) acc[j] = 0.f;
+            const int h0 = lo_h[ih], h1 = hi_h[ih], w0 = lo_w[iw], w1 = hi_w[iw];
+            const float* dc = dn + cv * VEC;
+            for (int od = d0; od <= d1; ++od) {
+                const float wd = up_weight(od, id, g.rd, g.di, g.mode, g.align_corners);
+                if (wd == 0.f) continue;
+                for (int oh = h0; oh <= h1; ++oh) {
+                    const float wh = wd * up_weight(oh, ih, g.rh, g.hi, g.mode, g.align_corners);
+                    if (wh == 0.f) continue;
+                    for (int ow = w0; ow <= w1; ++ow) {
+                        const float w = wh * up_weight(ow, iw, g.rw, g.wi, g.mode, g.align_corners);
+                        if (w == 0.f) continue;
+                        V<VEC> gv;
+                        gv.load(dc + (((int64_t)od * g.ho + oh) * g.wo + ow) * g.y_ld);
 #pragma unroll
-                    for (int j = 0; j < VEC; ++j) acc[j] = fmaf(w, gv.v[j], acc[j]);
+                        for (int j = 0; j < VEC; ++j) acc[j] = fmaf(w, gv.v[j], acc[j]);
+                    }
                 }
             }
-        }
-        V<VEC> o;
+            V<VEC> o;
 #pragma unroll
-        for (int j = 0; j < VEC; ++j) o.v[j] = acc[j];
-        o.store(dx + iv * g.x_ld + cv * VEC);
+            for (int j = 0; j < VEC; ++j) o.v[j] = acc[j];
+            o.store(dx + (ibase + pix) * g.x_ld + cv * VEC);
+        }
     }
+}
+
+// rows of H per slab so that one slab is ~8 passes of a 256-thread block, and the resulting grid size
+static inline void slab_plan(int nd, int h, int w, int cv, int& hch, int& grid) {
+    int64_t per_row = (int64_t)w * cv;
+    hch = (int)std::max<int64_t>(1, std::min<int64_t>(h, 2048 / std::max<int64_t>(per_row, 1)));
+    int64_t slabs = (int64_t)nd * ((h + hch - 1) / hch);
+    grid = (int)std::min<int64_t>(slabs, 8192);
 }
 
 static inline bool vec_ok(int c, int a_ld, int b_ld, const void* a, const void* b) {
@@ -319,12 +349,12 @@ extern "C" int mri3d_maxpool3d_fwd(const Mri3dPoolGeom* g, const void* x, void* 
     MRI3D_REQUIRE(x && y && idx, MRI3D_EINVAL, "maxpool3d_fwd: null pointer");
     hipStream_t s = static_cast<hipStream_t>(stream);
     bool v4 = vec_ok(g->c, g->x_ld, g->y_ld, x, y) && (reinterpret_cast<uintptr_t>(idx) & 3) == 0;
-    int64_t total = (int64_t)g->n * g->dout * g->ho * g->wo * (g->c / (v4 ? 4 : 1));
-    int grid = stream_grid(total, 256);
+    int hch, grid;
+    slab_plan(g->n * g->dout, g->ho, g->wo, g->c / (v4 ? 4 : 1), hch, grid);
     if (v4)
-        hipLaunchKernelGGL(maxpool_fwd_kernel<4>, dim3(grid), dim3(256), 0, s, *g, (const float*)x, (float*)y, idx);
+        hipLaunchKernelGGL(maxpool_fwd_kernel<4>, dim3(grid), dim3(256), 0, s, *g, (const float*)x, (float*)y, idx, hch);
     else
-        hipLaunchKernelGGL(maxpool_fwd_kernel<1>, dim3(grid), dim3(256), 0, s, *g, (const float*)x, (float*)y, idx);
+        hipLaunchKernelGGL(maxpool_fwd_kernel<1>, dim3(grid), dim3(256), 0, s, *g, (const float*)x, (float*)y, idx, hch);
     return check_launch("maxpool3d_fwd");
 }
 
@@ -335,12 +365,12 @@ extern "C" int mri3d_maxpool3d_bwd(const Mri3dPoolGeom* g, const void* dy, const
     MRI3D_REQUIRE(dy && dx && idx, MRI3D_EINVAL, "maxpool3d_bwd: null pointer");
     hipStream_t s = static_cast<hipStream_t>(stream);
     bool v4 = vec_ok(g->c, g->x_ld, g->y_ld, dx, dy) && (reinterpret_cast<uintptr_t>(idx) & 3) == 0;
-    int64_t total = (int64_t)g->n * g->di * g->hi * g->wi * (g->c / (v4 ? 4 : 1));
-    int grid = stream_grid(total, 256);
+    int hch, grid;
+    slab_plan(g->n * g->di, g->hi, g->wi, g->c / (v4 ? 4 : 1), hch, grid);
     if (v4)
-        hipLaunchKernelGGL(maxpool_bwd_kernel<4>, dim3(grid), dim3(256), 0, s, *g, (const float*)dy, idx, (float*)dx);
+        hipLaunchKernelGGL(maxpool_bwd_kernel<4>, dim3(grid), dim3(256), 0, s, *g, (const float*)dy, idx, (float*)dx, hch);
     else
-        hipLaunchKernelGGL(maxpool_bwd_kernel<1>, dim3(grid), dim3(256), 0, s, *g, (const float*)dy, idx, (float*)dx);
+        hipLaunchKernelGGL(maxpool_bwd_kernel<1>, dim3(grid), dim3(256), 0, s, *g, (const float*)dy, idx, (float*)dx, hch);
     return check_launch("maxpool3d_bwd");
 }
 
@@ -367,12 +397,12 @@ extern "C" int mri3d_upsample3d_fwd(const Mri3dUpGeom* g, const void* x, void* y
     MRI3D_REQUIRE(x && y, MRI3D_EINVAL, "upsample3d_fwd: null pointer");
     hipStream_t s = static_cast<hipStream_t>(stream);
     bool v4 = vec_ok(g->c, g->x_ld, g->y_ld, x, y);
-    int64_t total = (int64_t)g->n * g->dout * g->ho * g->wo * (g->c / (v4 ? 4 : 1));
-    int grid = stream_grid(total, 256);
+    int hch, grid;
+    slab_plan(g->n * g->dout, g->ho, g->wo, g->c / (v4 ? 4 : 1), hch, grid);
     if (v4)
-        hipLaunchKernelGGL(upsample_fwd_kernel<4>, dim3(grid), dim3(256), 0, s, *g, (const float*)x, (float*)y);
+        hipLaunchKernelGGL(upsample_fwd_kernel<4>, dim3(grid), dim3(256), 0, s, *g, (const float*)x, (float*)y, hch);
     else
-        hipLaunchKernelGGL(upsample_fwd_kernel<1>, dim3(grid), dim3(256), 0, s, *g, (const float*)x, (float*)y);
+        hipLaunchKernelGGL(upsample_fwd_kernel<1>, dim3(grid), dim3(256), 0, s, *g, (const float*)x, (float*)y, hch);
     return check_launch("upsample3d_fwd");
 }
 
@@ -387,11 +417,11 @@ extern "C" int mri3d_upsample3d_bwd(const Mri3dUpGeom* g, const void* dy, void* 
     int* tab = static_cast<int*>(workspace);
     hipLaunchKernelGGL(upsample_tables_kernel, dim3(3), dim3(256), 0, s, *g, tab);
     bool v4 = vec_ok(g->c, g->x_ld, g->y_ld, dx, dy);
-    int64_t total = (int64_t)g->n * g->di * g->hi * g->wi * (g->c / (v4 ? 4 : 1));
-    int grid = stream_grid(total, 256);
+    int hch, grid;
+    slab_plan(g->n * g->di, g->hi, g->wi, g->c / (v4 ? 4 : 1), hch, grid);
     if (v4)
-        hipLaunchKernelGGL(upsample_bwd_kernel<4>, dim3(grid), dim3(256), 0, s, *g, (const float*)dy, (float*)dx, tab);
+        hipLaunchKernelGGL(upsample_bwd_kernel<4>, dim3(grid), dim3(256), 0, s, *g, (const float*)dy, (float*)dx, tab, hch);
     else
-        hipLaunchKernelGGL(upsample_bwd_kernel<1>, dim3(grid), dim3(256), 0, s, *g, (const float*)dy, (float*)dx, tab);
+        hipLaunchKernelGGL(upsample_bwd_kernel<1>, dim3(grid), dim3(256), 0, s, *g, (const float*)dy, (float*)dx, tab, hch);
     return check_launch("upsample3d_bwd");
 }
