@@ -72,7 +72,8 @@ int mri3d_conv3d_wgrad(const Mri3dConvGeom* g, const void* x, const void* dy, vo
  * BatchNorm3d / InstanceNorm3d fused with the following activation — replaces
  * nn.BatchNorm3d + nn.PReLU (unet.UNet ConvolutionalBlock), nn.BatchNorm3d + LeakyReLU/ReLU
  * (AE_model.py:30-36, cnn_model.py), nn.InstanceNorm3d + LeakyReLU (modified_3dunet.py:20-94).
- * groups = 1 (batch norm: statistics over n*vox per channel) or n (instance norm: per (n,c)).
+ * groups = 1 (batch norm: statistics over n*vox per channel) or n (instance norm: per (n,c)); GroupNorm
+ * (nn.GroupNorm(4, C) of segmentation/models/unet3d.py:12) = instance mode with group_c = C/4 channels pooled.
  * ---------------------------------------------------------------------------------------------- */
 typedef struct Mri3dNormGeom {
     int32_t n;        /* batch */
@@ -85,6 +86,7 @@ typedef struct Mri3dNormGeom {
     int32_t alpha_n;  /* PReLU: number of alpha parameters (1 or c) */
     float slope;      /* LeakyReLU negative slope */
     float eps;
+    int32_t group_c;  /* GroupNorm: channels per group (needs instance = 1; statistics per (n, group)); 0 otherwise */
     int32_t dtype;
 } Mri3dNormGeom;
 

@@ -25,7 +25,7 @@ class ConvGeom(Structure):
 class NormGeom(Structure):
     _fields_ = [("n", c_int32), ("vox", c_int64), ("c", c_int32), ("x_ld", c_int32), ("y_ld", c_int32),
                 ("instance", c_int32), ("act", c_int32), ("alpha_n", c_int32), ("slope", c_float),
-                ("eps", c_float), ("dtype", c_int32)]
+                ("eps", c_float), ("group_c", c_int32), ("dtype", c_int32)]
 
 
 class PoolGeom(Structure):

@@ -168,6 +168,59 @@ norm_stats_finalize_kernel(const float* __restrict__ x, const double* __restrict
     }
 }
 
+// GroupNorm statistics: one thread per (n, group) pools the per-channel shifted moments of its group_c channels.
+//   per channel: s = sum(x - k), ss = sum((x - k)^2) with k = first voxel  =>  sum x = s + cnt*k, sum x^2 = ss + 2k*s + cnt*k^2
+__global__ void norm_stats_group_finalize_kernel(const float* __restrict__ x, const double* __restrict__ part,
+                                                 float* __restrict__ mean, float* __restrict__ invstd, float eps, int C,
+                                                 int ld, int64_t gvox, int nblk, int groups, int group_c) {
+    const int G = C / group_c;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= groups * G) return;
+    const int n = i / G, g = i - n * G;
+    double sx = 0.0, sxx = 0.0;
+    const double cnt = (double)gvox;
+    for (int c = g * group_c; c < (g + 1) * group_c; ++c) {
+        double a = 0.0, b = 0.0;
+        const double* p = part + ((size_t)n * nblk * C + c) * 2;
+        for (int q = 0; q < nblk; ++q) {
+            a += p[(size_t)q * C * 2];
+            b += p[(size_t)q * C * 2 + 1];
+        }
+        const double k = (double)x[(int64_t)n * gvox * ld + c];
+        sx += a + cnt * k;
+        sxx += b + 2.0 * k * a + cnt * k * k;
+    }
+    const double m = (double)group_c * cnt;
+    const double mu = sx / m;
+    double var = sxx / m - mu * mu;
+    if (var < 0.0) var = 0.0;
+    const float fm = (float)mu, fi = (float)(1.0 / sqrt(var + (double)eps));
+    for (int c = g * group_c; c < (g + 1) * group_c; ++c) {
+        mean[n * C + c] = fm;
+        invstd[n * C + c] = fi;
+    }
+}
+
+// GroupNorm backward: replace the per-(n,c) sums by the gamma-weighted sums of the channel's group (after dgamma/dbeta
+// have been taken from the per-channel sums).
+__global__ void norm_act_bwd_group_combine_kernel(float* __restrict__ sums, const float* __restrict__ gamma, int C,
+                                                  int groups, int group_c) {
+    const int G = C / group_c;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= groups * G) return;
+    const int n = i / G, g = i - n * G;
+    double g0 = 0.0, g1 = 0.0;
+    for (int c = g * group_c; c < (g + 1) * group_c; ++c) {
+        const double gm = gamma ? (double)gamma[c] : 1.0;
+        g0 += gm * (double)sums[((size_t)n * C + c) * 3];
+        g1 += gm * (double)sums[((size_t)n * C + c) * 3 + 1];
+    }
+    for (int c = g * group_c; c < (g + 1) * group_c; ++c) {
+        sums[((size_t)n * C + c) * 3] = (float)g0;
+        sums[((size_t)n * C + c) * 3 + 1] = (float)g1;
+    }
+}
+
 // ------------------------------------------------------------------ forward apply
 template <int VEC>
 __global__ void __launch_bounds__(256)
@@ -344,14 +397,14 @@ norm_act_bwd_apply_kernel(const float* __restrict__ x, const float* __restrict__
                           const float* __restrict__ sums, const float* __restrict__ mean,
                           const float* __restrict__ invstd, const float* __restrict__ gamma,
                           const float* __restrict__ beta, const float* __restrict__ alpha, int alpha_n, int act,
-                          float slope, int training, int C, int x_ld, int y_ld, int64_t gvox, int CL, int VT) {
+                          float slope, int training, int C, int x_ld, int y_ld, int64_t gvox, int CL, int VT, int group_c) {
     const int tid = threadIdx.x;
     const int cl = tid % CL, vt = tid / CL;
     const int c0 = (blockIdx.y * CL + cl) * VEC;
     if (vt >= VT || c0 >= C) return;
     const int group = blockIdx.z;
     float mu[VEC], is[VEC], gm[VEC], bt[VEC], al[VEC], k0[VEC], k1[VEC], k2[VEC];
-    const float invM = 1.f / (float)gvox;
+    const float invM = 1.f / ((float)gvox * (float)(group_c > 0 ? group_c : 1));
 #pragma unroll
     for (int j = 0; j < VEC; ++j) {
         int c = c0 + j;
@@ -364,8 +417,11 @@ norm_act_bwd_apply_kernel(const float* __restrict__ x, const float* __restrict__
         // dx = k0*du - k1 - xhat*k2
         k0[j] = gm[j] * is[j];
         if (training) {
-            k1[j] = k0[j] * sums[((size_t)group * C + c) * 3] * invM;
-            k2[j] = k0[j] * sums[((size_t)group * C + c) * 3 + 1] * invM;
+            // batch / instance norm: sums are per channel and scale with gamma*invstd; group norm: sums already hold the
+            // gamma-weighted totals of the channel's group and scale with invstd only
+            const float kk = group_c > 0 ? is[j] : k0[j];
+            k1[j] = kk * sums[((size_t)group * C + c) * 3] * invM;
+            k2[j] = kk * sums[((size_t)group * C + c) * 3 + 1] * invM;
         } else {
             k1[j] = 0.f;
             k2[j] = 0.f;
@@ -406,6 +462,8 @@ static int norm_check(const Mri3dNormGeom* g, const char* who) {
                   g->y_ld);
     MRI3D_REQUIRE(g->act != MRI3D_ACT_PRELU || g->alpha_n == 1 || g->alpha_n == g->c, MRI3D_EINVAL,
                   "%s: PReLU alpha_n=%d must be 1 or C=%d", who, g->alpha_n, g->c);
+    MRI3D_REQUIRE(g->group_c == 0 || (g->group_c > 0 && g->instance && g->c % g->group_c == 0), MRI3D_EINVAL,
+                  "%s: group_c=%d needs instance mode and must divide C=%d", who, g->group_c, g->c);
     return MRI3D_OK;
 }
 
@@ -431,6 +489,11 @@ extern "C" int mri3d_norm_stats(const Mri3dNormGeom* g, const void* x, float* me
     int tot = p.groups * g->c;
     hipLaunchKernelGGL(norm_stats_finalize_kernel, dim3(cdiv(tot, 256 / kFinQL)), dim3(256), 0, s, xf, part, mean, invstd,
                        running_mean, running_var, momentum, g->eps, g->c, g->x_ld, p.gvox, p.nblk, p.groups);
+    if (g->group_c > 0) {
+        const int ng = p.groups * (g->c / g->group_c);
+        hipLaunchKernelGGL(norm_stats_group_finalize_kernel, dim3(cdiv(ng, 64)), dim3(64), 0, s, xf, part, mean, invstd,
+                           g->eps, g->c, g->x_ld, p.gvox, p.nblk, p.groups, g->group_c);
+    }
     return check_launch("norm_stats");
 }
 
@@ -490,14 +553,19 @@ extern "C" int mri3d_norm_act_bwd(const Mri3dNormGeom* g, int training, const vo
         if (dgamma || dbeta || dalpha)
             hipLaunchKernelGGL(norm_act_bwd_params_kernel, dim3(1), dim3(256), 0, s, sums, dgamma, dbeta, dalpha,
                                g->alpha_n, g->c, p.groups);
+        if (g->group_c > 0 && training) {
+            const int ng = p.groups * (g->c / g->group_c);
+            hipLaunchKernelGGL(norm_act_bwd_group_combine_kernel, dim3(cdiv(ng, 64)), dim3(64), 0, s, sums, gamma, g->c,
+                               p.groups, g->group_c);
+        }
     }
     if (p.vec == 4)
         hipLaunchKernelGGL(norm_act_bwd_apply_kernel<4>, grid, dim3(256), 0, s, xf, df, of, sums, mean, invstd, gamma,
                            beta, alpha, g->alpha_n, g->act, g->slope, training, g->c, g->x_ld, g->y_ld, p.gvox, p.CL,
-                           p.VT);
+                           p.VT, g->group_c);
     else
         hipLaunchKernelGGL(norm_act_bwd_apply_kernel<1>, grid, dim3(256), 0, s, xf, df, of, sums, mean, invstd, gamma,
                            beta, alpha, g->alpha_n, g->act, g->slope, training, g->c, g->x_ld, g->y_ld, p.gvox, p.CL,
-                           p.VT);
+                           p.VT, g->group_c);
     return check_launch("norm_act_bwd");
 }

@@ -63,7 +63,15 @@ def fused_norm_act(norm, act, x, out=None):
         if norm.track_running_stats:
             raise NotImplementedError("InstanceNorm3d(track_running_stats=True) is not supported")
         return ops.norm_act(x, norm.weight, norm.bias, alpha, None, None, "instance", 0.1, norm.eps, kind, slope, out)
+    if isinstance(norm, tnn.GroupNorm):
+        return ops.norm_act(x, norm.weight, norm.bias, alpha, None, None, "group", 0.1, norm.eps, kind, slope, out,
+                            norm.num_channels // norm.num_groups)
     raise NotImplementedError("unsupported normalisation module %r" % (norm,))
+
+
+class GroupNorm(tnn.GroupNorm):
+    def forward(self, x):
+        return fused_norm_act(self, None, x)
 
 
 class BatchNorm3d(tnn.BatchNorm3d):
@@ -132,7 +140,7 @@ def run_fused(modules, x):
     while i < len(mods):
         m = mods[i]
         five_d = torch.is_tensor(x) and x.dim() == 5
-        if five_d and isinstance(m, (tnn.BatchNorm3d, tnn.InstanceNorm3d)):
+        if five_d and isinstance(m, (tnn.BatchNorm3d, tnn.InstanceNorm3d, tnn.GroupNorm)):
             nxt = mods[i + 1] if i + 1 < len(mods) else None
             if isinstance(nxt, _ACTS):
                 x = fused_norm_act(m, nxt, x)

@@ -277,7 +277,7 @@ def _channel_sum(t):
     """sum over (N,D,H,W) per channel with the norm-statistics kernel (mean * count)."""
     L = _lib.lib()
     n, c, d, h, w = t.shape
-    g = NormGeom(n, d * h * w, c, c, c, 0, ACT_NONE, 1, 0.0, 0.0, F32)
+    g = NormGeom(n, d * h * w, c, c, c, 0, ACT_NONE, 1, 0.0, 0.0, 0, F32)
     mean = torch.empty(c, dtype=torch.float32, device=t.device)
     invstd = torch.empty(c, dtype=torch.float32, device=t.device)
     ws = _workspace(L.mri3d_norm_workspace_bytes(ctypes.byref(g)), t.device)
@@ -340,7 +340,7 @@ class _NormActFn(torch.autograd.Function):
     """y = act(gamma * (x - mean) / sqrt(var + eps) + beta) with batch, instance, running or no statistics."""
 
     @staticmethod
-    def forward(ctx, x, gamma, beta, alpha, running_mean, running_var, stats_mode, momentum, eps, act, slope, out):
+    def forward(ctx, x, gamma, beta, alpha, running_mean, running_var, stats_mode, momentum, eps, act, slope, out, group_c=0):
         # stats_mode: "batch" (compute + update running), "instance", "running" (eval BN), "none" (activation only)
         # out: None, or (buffer, channel_offset): write y into that channel slice of a wider NDHWC buffer
         _require_device(x, gamma, beta, alpha)
@@ -349,7 +349,10 @@ class _NormActFn(torch.autograd.Function):
         n, c, d, h, w = x.shape
         act_code = _ACT_CODES[act]
         alpha_n = alpha.numel() if (act_code == ACT_PRELU) else 1
-        instance = 1 if stats_mode == "instance" else 0
+        instance = 1 if stats_mode in ("instance", "group") else 0
+        if stats_mode == "group" and (group_c <= 0 or c % group_c):
+            raise RuntimeError("group norm: channels per group %d must divide C=%d" % (group_c, c))
+        group_c = group_c if stats_mode == "group" else 0
         if out is None:
             y, y_ld, y_off = _new(x.shape, x), c, 0
         else:
@@ -359,9 +362,9 @@ class _NormActFn(torch.autograd.Function):
                 raise RuntimeError("norm_act(out=): buffer %s cannot hold a %s slice at channel %d"
                                    % (tuple(buf.shape), tuple(x.shape), y_off))
             y = _slice_view(buf, y_off, c)
-        g = NormGeom(n, d * h * w, c, x_ld, y_ld, instance, act_code, alpha_n, float(slope), float(eps), F32)
+        g = NormGeom(n, d * h * w, c, x_ld, y_ld, instance, act_code, alpha_n, float(slope), float(eps), group_c, F32)
         mean = invstd = None
-        if stats_mode in ("batch", "instance"):
+        if stats_mode in ("batch", "instance", "group"):
             groups = n if instance else 1
             mean = torch.empty(groups * c, dtype=torch.float32, device=x.device)
             invstd = torch.empty(groups * c, dtype=torch.float32, device=x.device)
@@ -380,7 +383,7 @@ class _NormActFn(torch.autograd.Function):
                   "norm_act_fwd")
         ctx.save_for_backward(x, mean, invstd, gamma, beta, alpha)
         ctx.geom = g
-        ctx.training_stats = stats_mode in ("batch", "instance")
+        ctx.training_stats = stats_mode in ("batch", "instance", "group")
         return y
 
     @staticmethod
@@ -393,7 +396,7 @@ class _NormActFn(torch.autograd.Function):
         if dx is None:  # dx shares x's pitch in the kernel: give it a dense x instead
             x = x.contiguous(memory_format=CL3D)
             dx = _new(x.shape, x)
-        g = NormGeom(g0.n, g0.vox, g0.c, g0.c, dy_ld, g0.instance, g0.act, g0.alpha_n, g0.slope, g0.eps, F32)
+        g = NormGeom(g0.n, g0.vox, g0.c, g0.c, dy_ld, g0.instance, g0.act, g0.alpha_n, g0.slope, g0.eps, g0.group_c, F32)
         dgamma = torch.empty_like(gamma) if (gamma is not None and ctx.needs_input_grad[1]) else None
         dbeta = torch.empty_like(beta) if (beta is not None and ctx.needs_input_grad[2]) else None
         prelu = g.act == ACT_PRELU
@@ -404,14 +407,15 @@ class _NormActFn(torch.autograd.Function):
                                        _ptr(invstd), _ptr(gamma), _ptr(beta), _ptr(alpha) if prelu else None, _ptr(dx),
                                        _ptr(dgamma), _ptr(dbeta), _ptr(dalpha), _ptr(ws), ws.numel(), _stream()),
                   "norm_act_bwd")
-        return dx, dgamma, dbeta, dalpha, None, None, None, None, None, None, None, None
+        return dx, dgamma, dbeta, dalpha, None, None, None, None, None, None, None, None, None
 
 
 def norm_act(x, gamma=None, beta=None, alpha=None, running_mean=None, running_var=None, stats_mode="batch",
-             momentum=0.1, eps=1e-5, act=None, slope=0.01, out=None):
+             momentum=0.1, eps=1e-5, act=None, slope=0.01, out=None, group_c=0):
     if momentum is None:
         raise RuntimeError("cumulative moving average (momentum=None) is not supported")
-    return _NormActFn.apply(x, gamma, beta, alpha, running_mean, running_var, stats_mode, momentum, eps, act, slope, out)
+    return _NormActFn.apply(x, gamma, beta, alpha, running_mean, running_var, stats_mode, momentum, eps, act, slope, out,
+                            group_c)
 
 
 def activation(x, act, alpha=None, slope=0.01):
@@ -427,7 +431,7 @@ class _ScaleInstanceFn(torch.autograd.Function):
         L = _lib.lib()
         x = _cl(x)
         n, c, d, h, w = x.shape
-        g = NormGeom(n, d * h * w, c, c, c, 1, ACT_NONE, 1, 0.0, 0.0, F32)
+        g = NormGeom(n, d * h * w, c, c, c, 1, ACT_NONE, 1, 0.0, 0.0, 0, F32)
         scale = scale.reshape(n * c).contiguous()
         zeros = torch.zeros_like(scale)
         y = _new(x.shape, x)

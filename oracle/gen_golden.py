@@ -183,6 +183,28 @@ def main():
              loss=np.array(per.mean().item()))
     print("dice known", per, per.mean().item())
 
+    # ---------------------------------------------------------------- unet3d.py ConvD / ConvU blocks (GroupNorm / BatchNorm / InstanceNorm)
+    import unet3d as R_U3            # noqa: E402  (reference, importable here; only its blocks are constructible)
+    from oracle import unet3d_blocks as O_U3
+    blocks = {}
+    for norm in ("gn", "bn", "in"):
+        torch.manual_seed(0); rd = R_U3.ConvD(4, 8, norm=norm)
+        torch.manual_seed(0); od = O_U3.ConvD(4, 8, norm=norm)
+        assert_same_state(rd, od)
+        xb = seeded_randn(1, (2, 4, 16, 16, 16))
+        yr, yo = rd(xb), od(xb)
+        assert torch.equal(yr, yo)
+        torch.manual_seed(0); ru = R_U3.ConvU(8, norm=norm)
+        torch.manual_seed(0); ou = O_U3.ConvU(8, norm=norm)
+        assert_same_state(ru, ou)
+        prev, xin = seeded_randn(2, (2, 4, 16, 16, 16)), seeded_randn(3, (2, 16, 8, 8, 8))
+        ur, uo = ru(xin, prev), ou(xin, prev)
+        assert torch.equal(ur, uo)
+        blocks["convd_" + norm] = yr.detach().flatten()[::37].numpy()
+        blocks["convu_" + norm] = ur.detach().flatten()[::37].numpy()
+    np.savez(os.path.join(OUT, "unet3d_blocks.npz"), **blocks)
+    print("unet3d blocks ok")
+
     # ---------------------------------------------------------------- unet.UNet (third-party): oracle + shipped checkpoint
     ck = "whole_im_train_seg_parc_epoch_7.pth"
     shutil.copyfile(os.path.join(REF, "segmentation", "weights", ck), os.path.join(OUT, "ckpt", ck))

@@ -256,6 +256,32 @@ def test_modified3dunet_train_mode_runs_with_dropout():
     assert tuple(out.shape) == (2, 2, 32, 32, 32) and torch.isfinite(out).all()
 
 
+# ------------------------------------------------------------------------------------------------ unet3d.py blocks
+@pytest.mark.parametrize("norm", ["gn", "bn", "in"])
+def test_unet3d_blocks_vs_oracle_and_golden(norm):
+    from mri_epilepsy_diagnosis_amd.segmentation.models import unet3d as P_U3
+    from oracle import unet3d_blocks as O_U3
+    gold = load_golden("unet3d_blocks.npz")
+    torch.manual_seed(0); od = O_U3.ConvD(4, 8, norm=norm)
+    torch.manual_seed(0); pd_ = P_U3.ConvD(4, 8, norm=norm)
+    x = seeded_randn(1, (2, 4, 16, 16, 16))
+    _compare(pd_, od, x, lambda o: o.square().mean(), lambda o: o.square().mean(), True)
+    with torch.no_grad():
+        pd_.load_state_dict(od.state_dict())   # _compare updated BN running stats in both; re-sync and compare to golden
+    torch.manual_seed(0); fresh = P_U3.ConvD(4, 8, norm=norm).to(DEV)
+    assert_close(to_ncdhw(fresh(x.to(DEV))).flatten()[::37], gold["convd_" + norm], what="ConvD vs golden")
+    torch.manual_seed(0); ou = O_U3.ConvU(8, norm=norm)
+    torch.manual_seed(0); pu = P_U3.ConvU(8, norm=norm).to(DEV)
+    prev, xin = seeded_randn(2, (2, 4, 16, 16, 16)), seeded_randn(3, (2, 16, 8, 8, 8))
+    yo = ou(xin, prev)
+    yp = pu(xin.to(DEV), prev.to(DEV))
+    assert_close(to_ncdhw(yp), yo.detach(), what="ConvU vs oracle")
+    assert_close(to_ncdhw(yp).flatten()[::37], gold["convu_" + norm], what="ConvU vs golden")
+    yo.square().mean().backward(); yp.square().mean().backward()
+    for (k, po), pp in zip(ou.named_parameters(), pu.parameters()):
+        assert_close(pp.grad.cpu(), po.grad, rel=5e-3, what="ConvU grad " + k)
+
+
 # ------------------------------------------------------------------------------------------------ full-size properties
 def test_full_size_unet_properties_160x192x160():
     """BASELINE configs[1] size (batch 2, fp32): shapes, finiteness, run-to-run bit determinism, loss in range,

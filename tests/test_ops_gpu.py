@@ -180,6 +180,27 @@ def test_norm_act_fwd_bwd(mode, act, c, alpha_n):
         assert_close(rv_d.cpu(), rv_r, rel=1e-5, what="running_var")
 
 
+@pytest.mark.parametrize("c,groups,act", [(8, 4, None), (16, 4, "relu"), (12, 3, "prelu"), (6, 1, None), (8, 8, "leaky_relu")])
+def test_group_norm_fwd_bwd(c, groups, act):
+    x = seeded_randn(1, (3, c, 5, 6, 7)) * 1.3 + 0.4
+    gamma, beta = seeded_randn(2, (c,)) * 0.5 + 1.0, seeded_randn(3, (c,)) * 0.3
+    alpha = torch.tensor([0.2])
+    xr, gr, br, ar = (t.clone().requires_grad_(True) for t in (x, gamma, beta, alpha))
+    yr = _ref_act(act, ar, 0.01)(F.group_norm(xr, groups, gr, br, 1e-5))
+    gy = seeded_randn(4, tuple(yr.shape))
+    yr.backward(gy)
+    xd, gd, bd = _dev(x), gamma.to(DEV).requires_grad_(True), beta.to(DEV).requires_grad_(True)
+    ad = alpha.to(DEV).requires_grad_(True) if act == "prelu" else None
+    yd = ops.norm_act(xd, gd, bd, ad, None, None, "group", 0.1, 1e-5, act, 0.01, None, c // groups)
+    yd.backward(_dev(gy, False))
+    assert_close(to_ncdhw(yd), yr, what="y")
+    assert_close(to_ncdhw(xd.grad), xr.grad, what="dx")
+    assert_close(gd.grad.cpu(), gr.grad, what="dgamma")
+    assert_close(bd.grad.cpu(), br.grad, what="dbeta")
+    if act == "prelu":
+        assert_close(ad.grad.cpu(), ar.grad, what="dalpha")
+
+
 def test_batch_stats_large_offset_is_stable():
     """mean >> std: the shifted-sum statistics must not lose the variance (E[x^2]-E[x]^2 cancellation)."""
     x = seeded_randn(1, (2, 8, 16, 16, 16)) * 0.05 + 300.0

@@ -74,6 +74,20 @@ def test_shipped_classification_checkpoints_strict_load_and_head_outputs():
     assert gold["sizes"].tolist() == [[192] * 3, [48] * 3, [12] * 3]  # block INPUT sizes (AE_model.py:47-48)
 
 
+@pytest.mark.parametrize("norm", ["gn", "bn", "in"])
+def test_unet3d_blocks_match_reference_vectors(norm):
+    from oracle import unet3d_blocks as O_U3
+    gold = load_golden("unet3d_blocks.npz")
+    torch.manual_seed(0)
+    d = O_U3.ConvD(4, 8, norm=norm)
+    np.testing.assert_allclose(d(seeded_randn(1, (2, 4, 16, 16, 16))).detach().flatten()[::37].numpy(), gold["convd_" + norm],
+                               rtol=1e-5, atol=1e-6)
+    torch.manual_seed(0)
+    u = O_U3.ConvU(8, norm=norm)
+    y = u(seeded_randn(3, (2, 16, 8, 8, 8)), seeded_randn(2, (2, 4, 16, 16, 16)))
+    np.testing.assert_allclose(y.detach().flatten()[::37].numpy(), gold["convu_" + norm], rtol=1e-5, atol=1e-6)
+
+
 def test_dice_known_answer():
     g = load_golden("dice_known.npz")
     lg, tg = torch.from_numpy(g["logits"]), torch.from_numpy(g["target"])
