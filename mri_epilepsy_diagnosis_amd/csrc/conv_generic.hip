@@ -306,26 +306,151 @@ conv_wgrad_generic_kernel(Mri3dConvGeom g, const float* __restrict__ x, const fl
 }
 
 // dw[co][ci][tap] = sum_b part[b][tap][ci][co]; dbias[co] = sum_b bias_part[b][co]
-__global__ void wgrad_reduce_kernel(const float* __restrict__ part, const float* __restrict__ bias_part,
-                                    float* __restrict__ dw, float* __restrict__ dbias, int nb, int taps, int Ci, int Co,
-                                    int CiP, int CoP) {
-    int total = Co * Ci * taps;
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < total) {
-        int tap = i % taps;
-        int ci = (i / taps) % Ci;
-        int co = i / (taps * Ci);
+// 32 lanes per output element stride over the per-block partials; lane sums are combined in a fixed order (double).
+__global__ void __launch_bounds__(256)
+wgrad_reduce_kernel(const float* __restrict__ part, const float* __restrict__ bias_part, float* __restrict__ dw,
+                    float* __restrict__ dbias, int nb, int taps, int Ci, int Co, int CiP, int CoP) {
+    __shared__ double red[256];
+    const int el = threadIdx.x >> 5, ql = threadIdx.x & 31;
+    const int nw = Co * Ci * taps, ntot = nw + (dbias != nullptr ? Co : 0);
+    const int i = blockIdx.x * 8 + el;
+    double s = 0.0;
+    if (i < nw) {
+        const int tap = i % taps, ci = (i / taps) % Ci, co = i / (taps * Ci);
         const float* p = part + ((size_t)tap * CiP + ci) * CoP + co;
         const size_t stride = (size_t)taps * CiP * CoP;
-        double s = 0.0;
-        for (int b = 0; b < nb; ++b) s += (double)p[b * stride];
-        dw[i] = (float)s;
+        for (int b = ql; b < nb; b += 32) s += (double)p[b * stride];
+    } else if (i < ntot) {
+        for (int b = ql; b < nb; b += 32) s += (double)bias_part[(size_t)b * Co + (i - nw)];
     }
-    if (dbias != nullptr && i < Co) {
-        double s = 0.0;
-        for (int b = 0; b < nb; ++b) s += (double)bias_part[(size_t)b * Co + i];
-        dbias[i] = (float)s;
+    red[threadIdx.x] = s;
+    __syncthreads();
+    if (ql == 0 && i < ntot) {
+        double t = 0.0;
+        for (int k = 0; k < 32; ++k) t += red[el * 32 + k];
+        if (i < nw) dw[i] = (float)t;
+        else dbias[i - nw] = (float)t;
     }
+}
+
+// ------------------------------------------------------------------ weight gradient, few-taps variant
+// Separable (k,1,1)/(1,k,1)/(1,1,k) convs (k <= 8 taps) with narrow channels are pure HBM streams: AI ~ 6 FLOP/B.  The
+// chunked kernel above spends its time on per-chunk barriers there (147 GB/s on the 6x1x1 1->8 layer).  Here a thread
+// owns (voxel lane, input channel): it walks output voxels grid-stride, reads dy[v][0..8) and its x value at every tap,
+// and keeps a taps x 8 block of dW in registers; lanes are combined through LDS (double) once per block, one partial
+// per block in the layout wgrad_reduce_kernel expects, fixed-order final sum => deterministic.
+constexpr int kSmTaps = 8, kSmCo = 8;
+
+__global__ void __launch_bounds__(256)
+conv_wgrad_small_kernel(Mri3dConvGeom g, const float* __restrict__ x, const float* __restrict__ dy,
+                        float* __restrict__ part, float* __restrict__ bias_part, int CiL, int CiP, int CoP) {
+    __shared__ float red[256 * kSmCo];
+    const int taps = g.kd * g.kh * g.kw;
+    const int tid = threadIdx.x;
+    const int cil = tid % CiL, vl = tid / CiL, VL = 256 / CiL;
+    const int ci = blockIdx.z * CiL + cil;
+    const int co0 = blockIdx.y * kSmCo;
+    const bool ci_ok = ci < g.ci;
+    const bool vec_dy = co0 + kSmCo <= g.co && (g.y_ld & 3) == 0 && ((uintptr_t)dy & 15) == 0;
+    float acc[kSmTaps][kSmCo], bsum[kSmCo];
+#pragma unroll
+    for (int t = 0; t < kSmTaps; ++t)
+#pragma unroll
+        for (int c = 0; c < kSmCo; ++c) acc[t][c] = 0.f;
+#pragma unroll
+    for (int c = 0; c < kSmCo; ++c) bsum[c] = 0.f;
+    const int64_t per_n = (int64_t)g.dout * g.ho * g.wo;
+    const int64_t nvox = (int64_t)g.n * per_n;
+    for (int64_t v = (int64_t)blockIdx.x * VL + vl; v < nvox; v += (int64_t)gridDim.x * VL) {
+        const int n = (int)(v / per_n);
+        unsigned r = (unsigned)(v - (int64_t)n * per_n);
+        const int ow = r % g.wo;
+        r /= g.wo;
+        const int oh = r % g.ho, od = r / g.ho;
+        float gv[kSmCo];
+        if (vec_dy) {
+            const float4* q = reinterpret_cast<const float4*>(dy + v * g.y_ld + co0);
+            const float4 a = q[0], b = q[1];
+            gv[0] = a.x, gv[1] = a.y, gv[2] = a.z, gv[3] = a.w, gv[4] = b.x, gv[5] = b.y, gv[6] = b.z, gv[7] = b.w;
+        } else {
+#pragma unroll
+            for (int c = 0; c < kSmCo; ++c) gv[c] = (co0 + c < g.co) ? dy[v * g.y_ld + co0 + c] : 0.f;
+        }
+        if (cil == 0) {
+#pragma unroll
+            for (int c = 0; c < kSmCo; ++c) bsum[c] += gv[c];
+        }
+        const float* xn = x + (int64_t)n * g.di * g.hi * g.wi * g.x_ld + ci;
+#pragma unroll
+        for (int t = 0; t < kSmTaps; ++t) {
+            if (t < taps) {
+                const int kw = t % g.kw, kh = (t / g.kw) % g.kh, kd = t / (g.kw * g.kh);
+                const int id = od * g.sd - g.pd + kd * g.dd, ih = oh * g.sh - g.ph + kh * g.dh, iw = ow * g.sw - g.pw + kw * g.dw;
+                const bool ok = ci_ok && (unsigned)id < (unsigned)g.di && (unsigned)ih < (unsigned)g.hi &&
+                                (unsigned)iw < (unsigned)g.wi;
+                const float xv = ok ? xn[(((int64_t)id * g.hi + ih) * g.wi + iw) * g.x_ld] : 0.f;
+#pragma unroll
+                for (int c = 0; c < kSmCo; ++c) acc[t][c] = fmaf(xv, gv[c], acc[t][c]);
+            }
+        }
+    }
+    // combine the VL voxel lanes of every (tap, ci) through LDS, in double, in a fixed order
+    for (int t = 0; t < taps; ++t) {
+        __syncthreads();
+#pragma unroll
+        for (int c = 0; c < kSmCo; ++c) {
+            float val = 0.f;
+#pragma unroll
+            for (int tt = 0; tt < kSmTaps; ++tt)
+                if (tt == t) val = acc[tt][c];
+            red[tid * kSmCo + c] = val;
+        }
+        __syncthreads();
+        for (int o = tid; o < CiL * kSmCo; o += 256) {
+            const int c = o % kSmCo, cl = o / kSmCo;
+            double sdbl = 0.0;
+            for (int l = 0; l < VL; ++l) sdbl += (double)red[(l * CiL + cl) * kSmCo + c];
+            const int cig = blockIdx.z * CiL + cl;
+            if (cig < g.ci && co0 + c < g.co)
+                part[(((size_t)blockIdx.x * taps + t) * CiP + cig) * CoP + co0 + c] = (float)sdbl;
+        }
+    }
+    if (bias_part != nullptr && blockIdx.z == 0) {
+        __syncthreads();
+#pragma unroll
+        for (int c = 0; c < kSmCo; ++c) red[tid * kSmCo + c] = (cil == 0) ? bsum[c] : 0.f;
+        __syncthreads();
+        if (tid < kSmCo && co0 + tid < g.co) {
+            double sdbl = 0.0;
+            for (int l = 0; l < VL; ++l) sdbl += (double)red[(l * CiL) * kSmCo + tid];
+            bias_part[(size_t)blockIdx.x * g.co + co0 + tid] = (float)sdbl;
+        }
+    }
+}
+
+static bool wgrad_small_ok(const Mri3dConvGeom& g) {
+    const int taps = g.kd * g.kh * g.kw;
+    return taps <= kSmTaps && g.ci <= 64 && g.co <= 64 && (int64_t)g.dout * g.ho * g.wo < 0x7fffffffLL;
+}
+
+struct WgradSmallPlan { int CiL, gz, gy, gx, CiP, CoP; size_t part_floats, bias_floats; };
+static WgradSmallPlan wgrad_small_plan(const Mri3dConvGeom& g) {
+    WgradSmallPlan p;
+    int cil = 1;
+    while (cil < g.ci && cil < 16) cil <<= 1;
+    p.CiL = cil;
+    p.gz = cdiv(g.ci, cil);
+    p.gy = cdiv(g.co, kSmCo);
+    p.CiP = cdiv(g.ci, 4) * 4;
+    p.CoP = cdiv(g.co, 4) * 4;
+    const int64_t nvox = (int64_t)g.n * g.dout * g.ho * g.wo;
+    int64_t want = cdiv64(nvox, (int64_t)(256 / cil) * 8);
+    int cap = 2048 / (p.gy * p.gz);
+    if (cap < 8) cap = 8;
+    p.gx = (int)std::max<int64_t>(1, std::min<int64_t>(want, cap));
+    p.part_floats = (size_t)p.gx * g.kd * g.kh * g.kw * p.CiP * p.CoP;
+    p.bias_floats = (size_t)p.gx * g.co;
+    return p;
 }
 
 // ------------------------------------------------------------------ host side
@@ -370,7 +495,12 @@ size_t conv_generic_workspace_bytes(const Mri3dConvGeom& g, int pass) {
         return (size_t)taps * g.co * cdiv(g.ci, t) * t * sizeof(float);
     }
     WgradPlan p = wgrad_plan(g);
-    return (p.part_floats + p.bias_floats) * sizeof(float);
+    size_t a = (p.part_floats + p.bias_floats) * sizeof(float);
+    if (wgrad_small_ok(g)) {
+        WgradSmallPlan q = wgrad_small_plan(g);
+        a = std::max(a, (q.part_floats + q.bias_floats) * sizeof(float));
+    }
+    return a;
 }
 
 template <int T>
@@ -440,6 +570,21 @@ int conv_generic_dgrad(const Mri3dConvGeom& g, const float* dy, const float* w, 
 
 int conv_generic_wgrad(const Mri3dConvGeom& g, const float* x, const float* dy, float* dw, float* dbias, void* ws,
                        size_t ws_bytes, hipStream_t s) {
+    if (wgrad_small_ok(g)) {
+        WgradSmallPlan q = wgrad_small_plan(g);
+        const size_t need = (q.part_floats + q.bias_floats) * sizeof(float);
+        MRI3D_REQUIRE(ws != nullptr && ws_bytes >= need, MRI3D_EWORKSPACE, "conv3d_wgrad: workspace %zu < %zu", ws_bytes, need);
+        float* part = static_cast<float*>(ws);
+        float* bias_part = dbias ? part + q.part_floats : nullptr;
+        const int taps = g.kd * g.kh * g.kw;
+        // partial slots of padded channels are never written by the kernel and never read by the reduce
+        hipLaunchKernelGGL(conv_wgrad_small_kernel, dim3(q.gx, q.gy, q.gz), dim3(256), 0, s, g, x, dy, part, bias_part,
+                           q.CiL, q.CiP, q.CoP);
+        const int total = g.co * g.ci * taps;
+        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(cdiv(total + g.co, 8)), dim3(256), 0, s, part, bias_part, dw,
+                           dbias, q.gx, taps, g.ci, g.co, q.CiP, q.CoP);
+        return check_launch("conv3d_wgrad(small)");
+    }
     WgradPlan p = wgrad_plan(g);
     size_t need = (p.part_floats + p.bias_floats) * sizeof(float);
     MRI3D_REQUIRE(ws != nullptr && ws_bytes >= need, MRI3D_EWORKSPACE, "conv3d_wgrad: workspace %zu < %zu", ws_bytes,
@@ -454,7 +599,7 @@ int conv_generic_wgrad(const Mri3dConvGeom& g, const float* x, const float* dy, 
     hipLaunchKernelGGL(conv_wgrad_generic_kernel, dim3(p.gx, p.taps, p.gz), dim3(256), p.smem, s, g, x, dy, part,
                        bias_part, p.Ci4, p.Co4, p.nitems, p.vsplit);
     int total = g.co * g.ci * p.taps;
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(cdiv(std::max(total, g.co), 256)), dim3(256), 0, s, part, bias_part, dw,
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(cdiv(total + g.co, 8)), dim3(256), 0, s, part, bias_part, dw,
                        dbias, p.gx, p.taps, g.ci, g.co, p.Ci4 * 4, p.Co4 * 4);
     return check_launch("conv3d_wgrad(generic)");
 }

@@ -1,0 +1,93 @@
+"""Throughput of the other BASELINE.json configurations (parity-test cases, not bench lines) on one MI355X:
+  cfg3  classification encoder (93_6_4 kwargs) + head, batch 4 x 160x192x160, CE step; and the full AE, MSE step
+  cfg5  CNN(32^3 patches), batch 512 (stand-in for the 2-D detection net)
+  m3d   Modified3DUNet(1,2,8), batch 1 x 160x192x160, soft-Dice step
+Prints ms/step, units/s and the per-operator device-time table (top N)."""
+import os
+import sys
+import time
+
+import torch
+import torch.nn.functional as F
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+from mri_epilepsy_diagnosis_amd import ops  # noqa: E402
+from mri_epilepsy_diagnosis_amd.classification.models import AE_model, cnn_model  # noqa: E402
+from mri_epilepsy_diagnosis_amd.segmentation.models.modified_3dunet import Modified3DUNet  # noqa: E402
+from util import AE_KWARGS_93_6_4, CLF_KWARGS  # noqa: E402
+
+dev = torch.device("cuda")
+which = sys.argv[1] if len(sys.argv) > 1 else "all"
+TOP = int(os.environ.get("TOP", "12"))
+
+
+def run(name, units, step, steps=5, warmup=2):
+    for _ in range(warmup):
+        step()
+    torch.cuda.synchronize()
+    timer = ops.KernelTimer()
+    ops.set_timer(timer)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    ops.set_timer(None)
+    print("== %s: %.2f ms/step, %.1f units/s" % (name, dt * 1e3, units / dt), flush=True)
+    agg = timer.summary()
+    tot = sum(a["ms"] for a in agg.values())
+    for tag, a in sorted(agg.items(), key=lambda kv: -kv[1]["ms"])[:TOP]:
+        w = a["work"] or {}
+        print("   %8.3f ms/step %5.1f%% %7.2f TF/s %8.1f GB/s x%-3d %s" % (
+            a["ms"] / steps, 100 * a["ms"] / tot, w.get("flops", 0) * a["calls"] / (a["ms"] / 1e3) / 1e12,
+            w.get("bytes", 0) * a["calls"] / (a["ms"] / 1e3) / 1e9, a["calls"] // steps, tag))
+
+
+g = torch.Generator(device=dev).manual_seed(0)
+if which in ("all", "cfg3"):
+    torch.manual_seed(0)
+    enc = AE_model.AE(**AE_KWARGS_93_6_4).enc.to(dev)
+    clf = AE_model.Classificator(**dict(CLF_KWARGS, conv_pad=1, l_in=64 * 2 * 3 * 2)).to(dev)
+    opt = torch.optim.Adam(list(enc.parameters()) + list(clf.parameters()), lr=7e-4, weight_decay=1e-4)
+    x = torch.randn(4, 1, 160, 192, 160, device=dev, generator=g)
+    y = torch.randint(0, 2, (4,), device=dev, generator=g)
+
+    def step3():
+        opt.zero_grad()
+        lat, _ = enc(x)
+        F.cross_entropy(clf(lat), y).backward()
+        opt.step()
+    run("cfg3 encoder+clf CE step, 4 x 160x192x160", 4, step3)
+    ae = AE_model.AE(**AE_KWARGS_93_6_4).to(dev)
+    opt2 = torch.optim.Adam(ae.parameters(), lr=1e-3)
+
+    def step3b():
+        opt2.zero_grad()
+        F.mse_loss(ae(x), x).backward()
+        opt2.step()
+    run("cfg3 full AE MSE step, 4 x 160x192x160", 4, step3b)
+if which in ("all", "cfg5"):
+    torch.manual_seed(0)
+    net = torch.nn.Sequential(cnn_model.CNN(input_shape=(32, 32, 32), n_filters=16, n_blocks=3), torch.nn.Linear(128, 2)).to(dev)
+    opt = torch.optim.Adam(net.parameters(), lr=1e-5, weight_decay=0.01)
+    x5 = torch.randn(512, 1, 32, 32, 32, device=dev, generator=g)
+    y5 = torch.randint(0, 2, (512,), device=dev, generator=g)
+
+    def step5():
+        opt.zero_grad()
+        F.cross_entropy(net(x5), y5).backward()
+        opt.step()
+    run("cfg5 CNN 32^3 patches, batch 512", 512, step5)
+if which in ("all", "m3d"):
+    torch.manual_seed(0)
+    m = Modified3DUNet(1, 2, 8).to(dev)
+    opt = torch.optim.AdamW(m.parameters())
+    x6 = torch.randn(1, 1, 160, 192, 160, device=dev, generator=g)
+    t6 = (torch.rand(1, 1, 160, 192, 160, device=dev, generator=g) < 0.1).float()
+
+    def step6():
+        opt.zero_grad()
+        ops.softmax_dice_loss(m(x6), t6).backward()
+        opt.step()
+    run("Modified3DUNet(1,2,8) dice step, 1 x 160x192x160", 1, step6)
