@@ -14,7 +14,8 @@
  *     slice of a wider buffer (decoder concat buffers) without a copy.
  *   - Weights keep torch's parameter layout (Cout, Cin, kd, kh, kw) so state_dicts stay compatible;
  *     kernels repack into `workspace` on the fly.
- *   - dtype: MRI3D_F32 only in this revision (MRI3D_BF16 is reserved and returns MRI3D_ENOTSUP).
+ *   - dtype: storage type of the ACTIVATION tensors (x, y, dy, dx, logits ...): MRI3D_F32, or MRI3D_BF16 (bfloat16
+ *     storage, fp32 arithmetic and accumulation).  Parameters, statistics, parameter gradients, losses are always fp32.
  *   - Return value: 0 = OK, negative = error; mri3d_last_error() gives a thread-local message.
  *   - Reductions are deterministic (no floating-point atomics).
  */
@@ -174,6 +175,10 @@ int mri3d_copy_channels(const void* src, void* dst, int64_t nvox, int32_t c, int
                         int32_t dtype, mri3d_stream_t stream);
 int mri3d_add_channels(const void* a, const void* b, void* dst, int64_t nvox, int32_t c, int32_t a_ld,
                        int32_t b_ld, int32_t dst_ld, int32_t dtype, mri3d_stream_t stream);
+/* Storage-type cast at the edge of a bf16 region (the `.to(bfloat16)` / `.float()` an autocast region inserts;
+ * BASELINE configs[3]): dst[v, 0:c] = (dst_dtype) src[v, 0:c], round-to-nearest-even towards bf16. */
+int mri3d_convert_channels(const void* src, int32_t src_dtype, void* dst, int32_t dst_dtype, int64_t nvox, int32_t c,
+                           int32_t src_ld, int32_t dst_ld, mri3d_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * AdamW / Adam on one flat fp32 buffer — torch.optim.AdamW (segmentation/routine.py:358) and

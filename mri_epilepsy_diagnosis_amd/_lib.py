@@ -72,6 +72,7 @@ SIGNATURES = {
     "mri3d_argmax_u8": (c_int32, [_P, _P, c_int64, c_int32, c_int32, c_int32, _P]),
     "mri3d_copy_channels": (c_int32, [_P, _P, c_int64, c_int32, c_int32, c_int32, c_int32, _P]),
     "mri3d_add_channels": (c_int32, [_P, _P, _P, c_int64, c_int32, c_int32, c_int32, c_int32, c_int32, _P]),
+    "mri3d_convert_channels": (c_int32, [_P, c_int32, _P, c_int32, c_int64, c_int32, c_int32, c_int32, _P]),
     "mri3d_adam_step": (c_int32, [_FP, _FP, _FP, _FP, c_int64, c_float, c_float, c_float, c_float, c_float, c_int32,
                                   c_float, c_int32, _P]),
 }

@@ -16,33 +16,34 @@ void set_error(const char* fmt, ...) {
 
 // conv_generic.hip
 size_t conv_generic_workspace_bytes(const Mri3dConvGeom& g, int pass);
-int conv_generic_fwd(const Mri3dConvGeom& g, const float* x, const float* w, const float* bias, float* y, void* ws,
+// activations (x, y, dy, dx) are in the storage type g.dtype; weights, bias and their gradients are fp32
+int conv_generic_fwd(const Mri3dConvGeom& g, const void* x, const float* w, const float* bias, void* y, void* ws,
                      size_t ws_bytes, hipStream_t s);
-int conv_generic_dgrad(const Mri3dConvGeom& g, const float* dy, const float* w, const float* bias, float* dx, void* ws,
+int conv_generic_dgrad(const Mri3dConvGeom& g, const void* dy, const float* w, const float* bias, void* dx, void* ws,
                        size_t ws_bytes, hipStream_t s);
-int conv_generic_wgrad(const Mri3dConvGeom& g, const float* x, const float* dy, float* dw, float* dbias, void* ws,
+int conv_generic_wgrad(const Mri3dConvGeom& g, const void* x, const void* dy, float* dw, float* dbias, void* ws,
                        size_t ws_bytes, hipStream_t s);
 // conv_mfma.hip
 bool conv_mfma_supported(const Mri3dConvGeom& g, int pass);
 size_t conv_mfma_workspace_bytes(const Mri3dConvGeom& g, int pass);
-int conv_mfma_fwd(const Mri3dConvGeom& g, const float* x, const float* w, const float* bias, float* y, void* ws,
+int conv_mfma_fwd(const Mri3dConvGeom& g, const void* x, const float* w, const float* bias, void* y, void* ws,
                   size_t ws_bytes, hipStream_t s);
-int conv_mfma_dgrad(const Mri3dConvGeom& g, const float* dy, const float* w, const float* bias, float* dx, void* ws,
+int conv_mfma_dgrad(const Mri3dConvGeom& g, const void* dy, const float* w, const float* bias, void* dx, void* ws,
                     size_t ws_bytes, hipStream_t s);
-int conv_mfma_wgrad(const Mri3dConvGeom& g, const float* x, const float* dy, float* dw, float* dbias, void* ws,
+int conv_mfma_wgrad(const Mri3dConvGeom& g, const void* x, const void* dy, float* dw, float* dbias, void* ws,
                     size_t ws_bytes, hipStream_t s);
 
 // conv_pointwise.hip
 bool conv_pointwise_supported(const Mri3dConvGeom& g, int pass);
 size_t conv_pointwise_workspace_bytes(const Mri3dConvGeom& g, int pass);
-int conv_pointwise_dgrad(const Mri3dConvGeom& g, const float* dy, const float* w, const float* bias, float* dx,
+int conv_pointwise_dgrad(const Mri3dConvGeom& g, const void* dy, const float* w, const float* bias, void* dx,
                          hipStream_t s);
-int conv_pointwise_wgrad(const Mri3dConvGeom& g, const float* x, const float* dy, float* dw, float* dbias, void* ws,
+int conv_pointwise_wgrad(const Mri3dConvGeom& g, const void* x, const void* dy, float* dw, float* dbias, void* ws,
                          size_t ws_bytes, hipStream_t s);
 
 static int conv_check(const Mri3dConvGeom* g, const char* who) {
     MRI3D_REQUIRE(g != nullptr, MRI3D_EINVAL, "%s: null geometry", who);
-    MRI3D_REQUIRE(g->dtype == MRI3D_F32, MRI3D_ENOTSUP, "%s: only MRI3D_F32 is implemented (dtype=%d)", who, g->dtype);
+    MRI3D_REQUIRE(g->dtype == MRI3D_F32 || g->dtype == MRI3D_BF16, MRI3D_ENOTSUP, "%s: unknown dtype %d", who, g->dtype);
     MRI3D_REQUIRE(g->n > 0 && g->di > 0 && g->hi > 0 && g->wi > 0 && g->ci > 0 && g->dout > 0 && g->ho > 0 && g->wo > 0 &&
                       g->co > 0,
                   MRI3D_EINVAL, "%s: empty tensor", who);
@@ -83,8 +84,8 @@ extern "C" int mri3d_conv3d_fwd(const Mri3dConvGeom* g, const void* x, const voi
     MRI3D_REQUIRE(x && w && y, MRI3D_EINVAL, "conv3d_fwd: null pointer");
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (conv_mfma_supported(*g, MRI3D_PASS_FWD))
-        return conv_mfma_fwd(*g, (const float*)x, (const float*)w, (const float*)bias, (float*)y, workspace, ws_bytes, s);
-    return conv_generic_fwd(*g, (const float*)x, (const float*)w, (const float*)bias, (float*)y, workspace, ws_bytes, s);
+        return conv_mfma_fwd(*g, x, (const float*)w, (const float*)bias, y, workspace, ws_bytes, s);
+    return conv_generic_fwd(*g, x, (const float*)w, (const float*)bias, y, workspace, ws_bytes, s);
 }
 
 extern "C" int mri3d_conv3d_dgrad(const Mri3dConvGeom* g, const void* dy, const void* w, const void* bias, void* dx,
@@ -93,11 +94,11 @@ extern "C" int mri3d_conv3d_dgrad(const Mri3dConvGeom* g, const void* dy, const 
     if (rc) return rc;
     MRI3D_REQUIRE(dy && w && dx, MRI3D_EINVAL, "conv3d_dgrad: null pointer");
     hipStream_t s = static_cast<hipStream_t>(stream);
-    if (conv_pointwise_supported(*g, MRI3D_PASS_DGRAD) && (reinterpret_cast<uintptr_t>(dx) & 15) == 0)
-        return conv_pointwise_dgrad(*g, (const float*)dy, (const float*)w, (const float*)bias, (float*)dx, s);
+    if (conv_pointwise_supported(*g, MRI3D_PASS_DGRAD) && aligned_vec4(g->dtype, dx))
+        return conv_pointwise_dgrad(*g, dy, (const float*)w, (const float*)bias, dx, s);
     if (conv_mfma_supported(*g, MRI3D_PASS_DGRAD))
-        return conv_mfma_dgrad(*g, (const float*)dy, (const float*)w, (const float*)bias, (float*)dx, workspace, ws_bytes, s);
-    return conv_generic_dgrad(*g, (const float*)dy, (const float*)w, (const float*)bias, (float*)dx, workspace, ws_bytes, s);
+        return conv_mfma_dgrad(*g, dy, (const float*)w, (const float*)bias, dx, workspace, ws_bytes, s);
+    return conv_generic_dgrad(*g, dy, (const float*)w, (const float*)bias, dx, workspace, ws_bytes, s);
 }
 
 extern "C" int mri3d_conv3d_wgrad(const Mri3dConvGeom* g, const void* x, const void* dy, void* dw, void* dbias,
@@ -106,9 +107,9 @@ extern "C" int mri3d_conv3d_wgrad(const Mri3dConvGeom* g, const void* x, const v
     if (rc) return rc;
     MRI3D_REQUIRE(x && dy && dw, MRI3D_EINVAL, "conv3d_wgrad: null pointer");
     hipStream_t s = static_cast<hipStream_t>(stream);
-    if (conv_pointwise_supported(*g, MRI3D_PASS_WGRAD) && (reinterpret_cast<uintptr_t>(x) & 15) == 0)
-        return conv_pointwise_wgrad(*g, (const float*)x, (const float*)dy, (float*)dw, (float*)dbias, workspace, ws_bytes, s);
+    if (conv_pointwise_supported(*g, MRI3D_PASS_WGRAD) && aligned_vec4(g->dtype, x))
+        return conv_pointwise_wgrad(*g, x, dy, (float*)dw, (float*)dbias, workspace, ws_bytes, s);
     if (conv_mfma_supported(*g, MRI3D_PASS_WGRAD))
-        return conv_mfma_wgrad(*g, (const float*)x, (const float*)dy, (float*)dw, (float*)dbias, workspace, ws_bytes, s);
-    return conv_generic_wgrad(*g, (const float*)x, (const float*)dy, (float*)dw, (float*)dbias, workspace, ws_bytes, s);
+        return conv_mfma_wgrad(*g, x, dy, (float*)dw, (float*)dbias, workspace, ws_bytes, s);
+    return conv_generic_wgrad(*g, x, dy, (float*)dw, (float*)dbias, workspace, ws_bytes, s);
 }

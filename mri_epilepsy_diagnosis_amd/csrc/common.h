@@ -41,6 +41,48 @@ inline int stream_grid(int64_t work_items, int per_block) {
     return (int)b;
 }
 
+// ---------------------------------------------------------------- storage types
+// Activations are stored as float (MRI3D_F32) or bfloat16 (MRI3D_BF16, BASELINE configs[3]); arithmetic, statistics,
+// parameters and parameter gradients are always fp32.  gfx950 converts with v_cvt_pk_bf16_f32 (round-to-nearest-even).
+typedef __bf16 bf16_t;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4_t;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+
+template <typename T> __device__ __forceinline__ float ldf(const T* p) { return (float)*p; }
+template <typename T> __device__ __forceinline__ void stf(T* p, float v) { *p = (T)v; }
+
+// 4 consecutive elements; p must be aligned to 4 elements (16 B for float, 8 B for bf16)
+__device__ __forceinline__ float4 ldf4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ float4 ldf4(const bf16_t* p) {
+    const bf16x4_t v = *reinterpret_cast<const bf16x4_t*>(p);
+    return make_float4((float)v[0], (float)v[1], (float)v[2], (float)v[3]);
+}
+__device__ __forceinline__ void stf4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
+__device__ __forceinline__ void stf4(bf16_t* p, float4 v) {
+    bf16x4_t o;
+    o[0] = (bf16_t)v.x, o[1] = (bf16_t)v.y, o[2] = (bf16_t)v.z, o[3] = (bf16_t)v.w;
+    *reinterpret_cast<bf16x4_t*>(p) = o;
+}
+
+inline size_t dtype_size(int dtype) { return dtype == MRI3D_BF16 ? 2 : 4; }
+// all pointers aligned for 4-element vector access in the given storage type
+inline bool aligned_vec4(int dtype, const void* a, const void* b = nullptr, const void* c = nullptr) {
+    const uintptr_t m = dtype == MRI3D_BF16 ? 7 : 15;
+    return ((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(b) | reinterpret_cast<uintptr_t>(c)) & m) == 0;
+}
+
+// Run `body` with `T` bound to the storage type of `dtype`.
+#define MRI3D_DISPATCH_DTYPE(dtype, T, ...)  \
+    do {                                     \
+        if ((dtype) == MRI3D_BF16) {         \
+            using T = ::mri3d::bf16_t;       \
+            __VA_ARGS__                      \
+        } else {                             \
+            using T = float;                 \
+            __VA_ARGS__                      \
+        }                                    \
+    } while (0)
+
 // ---------------------------------------------------------------- device helpers
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

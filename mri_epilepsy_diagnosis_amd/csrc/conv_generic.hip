@@ -35,10 +35,10 @@ __global__ void repack_w_dgrad_kernel(const float* __restrict__ w, float* __rest
 
 // ------------------------------------------------------------------ forward
 // One thread = one output voxel x COT output channels.  Weights are wave-uniform -> scalar loads.
-template <int COT, bool VEC4>
+template <typename T, int COT, bool VEC4>
 __global__ void __launch_bounds__(256)
-conv_fwd_generic_kernel(Mri3dConvGeom g, const float* __restrict__ x, const float* __restrict__ wp,
-                        const float* __restrict__ bias, float* __restrict__ y, int CoP) {
+conv_fwd_generic_kernel(Mri3dConvGeom g, const T* __restrict__ x, const float* __restrict__ wp,
+                        const float* __restrict__ bias, T* __restrict__ y, int CoP) {
     const int cot = blockIdx.y * COT;
     const int64_t nvox = (int64_t)g.n * g.dout * g.ho * g.wo;
     for (int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; v < nvox; v += (int64_t)gridDim.x * blockDim.x) {
@@ -60,12 +60,12 @@ conv_fwd_generic_kernel(Mri3dConvGeom g, const float* __restrict__ x, const floa
                     int iw = ow * g.sw - g.pw + kw * g.dw;
                     bool valid = (unsigned)id < (unsigned)g.di && (unsigned)ih < (unsigned)g.hi &&
                                  (unsigned)iw < (unsigned)g.wi;
-                    const float* xp = x + ((((int64_t)n * g.di + (valid ? id : 0)) * g.hi + (valid ? ih : 0)) * g.wi +
+                    const T* xp = x + ((((int64_t)n * g.di + (valid ? id : 0)) * g.hi + (valid ? ih : 0)) * g.wi +
                                            (valid ? iw : 0)) * g.x_ld;
                     const float* wt = wp + (size_t)tap * g.ci * CoP + cot;
                     if (VEC4) {
                         for (int ci = 0; ci < g.ci; ci += 4) {
-                            float4 xv = valid ? *reinterpret_cast<const float4*>(xp + ci) : make_float4(0, 0, 0, 0);
+                            float4 xv = valid ? ldf4(xp + ci) : make_float4(0, 0, 0, 0);
                             const float* w0 = wt + (size_t)ci * CoP;
 #pragma unroll
                             for (int j = 0; j < COT; ++j) {
@@ -77,7 +77,7 @@ conv_fwd_generic_kernel(Mri3dConvGeom g, const float* __restrict__ x, const floa
                         }
                     } else {
                         for (int ci = 0; ci < g.ci; ++ci) {
-                            float xv = valid ? xp[ci] : 0.f;
+                            float xv = valid ? ldf(xp + ci) : 0.f;
                             const float* w0 = wt + (size_t)ci * CoP;
 #pragma unroll
                             for (int j = 0; j < COT; ++j) acc[j] = fmaf(xv, w0[j], acc[j]);
@@ -86,19 +86,19 @@ conv_fwd_generic_kernel(Mri3dConvGeom g, const float* __restrict__ x, const floa
                 }
             }
         }
-        float* yp = y + v * g.y_ld + cot;
+        T* yp = y + v * g.y_ld + cot;
 #pragma unroll
         for (int j = 0; j < COT; ++j)
-            if (cot + j < g.co) yp[j] = acc[j];
+            if (cot + j < g.co) stf(yp + j, acc[j]);
     }
 }
 
 // ------------------------------------------------------------------ data gradient (also ConvTranspose3d forward)
 // One thread = one input voxel x CIT input channels; gather over the output voxels that read it.
-template <int CIT, bool VEC4>
+template <typename T, int CIT, bool VEC4>
 __global__ void __launch_bounds__(256)
-conv_dgrad_generic_kernel(Mri3dConvGeom g, const float* __restrict__ dy, const float* __restrict__ wp,
-                          const float* __restrict__ bias, float* __restrict__ dx, int CiP) {
+conv_dgrad_generic_kernel(Mri3dConvGeom g, const T* __restrict__ dy, const float* __restrict__ wp,
+                          const float* __restrict__ bias, T* __restrict__ dx, int CiP) {
     const int cit = blockIdx.y * CIT;
     const int64_t nvox = (int64_t)g.n * g.di * g.hi * g.wi;
     for (int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; v < nvox; v += (int64_t)gridDim.x * blockDim.x) {
@@ -124,12 +124,12 @@ conv_dgrad_generic_kernel(Mri3dConvGeom g, const float* __restrict__ dy, const f
                     int nw = iw + g.pw - kw * g.dw;
                     int ow = nw / g.sw;
                     bool valid = vd && vh && nw >= 0 && (nw - ow * g.sw) == 0 && ow < g.wo;
-                    const float* yp = dy + ((((int64_t)n * g.dout + (valid ? od : 0)) * g.ho + (valid ? oh : 0)) * g.wo +
+                    const T* yp = dy + ((((int64_t)n * g.dout + (valid ? od : 0)) * g.ho + (valid ? oh : 0)) * g.wo +
                                             (valid ? ow : 0)) * g.y_ld;
                     const float* wt = wp + (size_t)tap * g.co * CiP + cit;
                     if (VEC4) {
                         for (int co = 0; co < g.co; co += 4) {
-                            float4 gv = valid ? *reinterpret_cast<const float4*>(yp + co) : make_float4(0, 0, 0, 0);
+                            float4 gv = valid ? ldf4(yp + co) : make_float4(0, 0, 0, 0);
                             const float* w0 = wt + (size_t)co * CiP;
 #pragma unroll
                             for (int j = 0; j < CIT; ++j) {
@@ -141,7 +141,7 @@ conv_dgrad_generic_kernel(Mri3dConvGeom g, const float* __restrict__ dy, const f
                         }
                     } else {
                         for (int co = 0; co < g.co; ++co) {
-                            float gv = valid ? yp[co] : 0.f;
+                            float gv = valid ? ldf(yp + co) : 0.f;
                             const float* w0 = wt + (size_t)co * CiP;
 #pragma unroll
                             for (int j = 0; j < CIT; ++j) acc[j] = fmaf(gv, w0[j], acc[j]);
@@ -150,10 +150,10 @@ conv_dgrad_generic_kernel(Mri3dConvGeom g, const float* __restrict__ dy, const f
                 }
             }
         }
-        float* xp = dx + v * g.x_ld + cit;
+        T* xp = dx + v * g.x_ld + cit;
 #pragma unroll
         for (int j = 0; j < CIT; ++j)
-            if (cit + j < g.ci) xp[j] = acc[j];
+            if (cit + j < g.ci) stf(xp + j, acc[j]);
     }
 }
 
@@ -165,8 +165,9 @@ conv_dgrad_generic_kernel(Mri3dConvGeom g, const float* __restrict__ dy, const f
 constexpr int kWgCH = 64;   // output voxels per chunk
 constexpr int kWgIPT = 4;   // 4x4 items per thread (when Ci4*Co4 > 256)
 
+template <typename T>
 __global__ void __launch_bounds__(256)
-conv_wgrad_generic_kernel(Mri3dConvGeom g, const float* __restrict__ x, const float* __restrict__ dy,
+conv_wgrad_generic_kernel(Mri3dConvGeom g, const T* __restrict__ x, const T* __restrict__ dy,
                           float* __restrict__ part, float* __restrict__ bias_part, int Ci4, int Co4, int nitems,
                           int vsplit) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -230,12 +231,12 @@ conv_wgrad_generic_kernel(Mri3dConvGeom g, const float* __restrict__ x, const fl
         for (int i = tid; i < kWgCH * CoP; i += 256) {
             int vv = i / CoP, c = i - vv * CoP;
             int64_t v = v0 + vv;
-            dy_s[i] = (v < nvox && c < g.co) ? dy[v * g.y_ld + c] : 0.f;
+            dy_s[i] = (v < nvox && c < g.co) ? ldf(dy + v * g.y_ld + c) : 0.f;
         }
         for (int i = tid; i < kWgCH * CiP; i += 256) {
             int vv = i / CiP, c = i - vv * CiP;
             int64_t off = off_s[vv];
-            x_s[i] = (off >= 0 && c < g.ci) ? x[off + c] : 0.f;
+            x_s[i] = (off >= 0 && c < g.ci) ? ldf(x + off + c) : 0.f;
         }
         __syncthreads();
         if (do_bias && tid < g.co) {
@@ -341,8 +342,9 @@ wgrad_reduce_kernel(const float* __restrict__ part, const float* __restrict__ bi
 // per block in the layout wgrad_reduce_kernel expects, fixed-order final sum => deterministic.
 constexpr int kSmTaps = 8, kSmCo = 8;
 
+template <typename T>
 __global__ void __launch_bounds__(256)
-conv_wgrad_small_kernel(Mri3dConvGeom g, const float* __restrict__ x, const float* __restrict__ dy,
+conv_wgrad_small_kernel(Mri3dConvGeom g, const T* __restrict__ x, const T* __restrict__ dy,
                         float* __restrict__ part, float* __restrict__ bias_part, int CiL, int CiP, int CoP) {
     __shared__ float red[256 * kSmCo];
     const int taps = g.kd * g.kh * g.kw;
@@ -351,7 +353,7 @@ conv_wgrad_small_kernel(Mri3dConvGeom g, const float* __restrict__ x, const floa
     const int ci = blockIdx.z * CiL + cil;
     const int co0 = blockIdx.y * kSmCo;
     const bool ci_ok = ci < g.ci;
-    const bool vec_dy = co0 + kSmCo <= g.co && (g.y_ld & 3) == 0 && ((uintptr_t)dy & 15) == 0;
+    const bool vec_dy = co0 + kSmCo <= g.co && (g.y_ld & 3) == 0 && ((uintptr_t)dy & (4 * sizeof(T) - 1)) == 0;
     float acc[kSmTaps][kSmCo], bsum[kSmCo];
 #pragma unroll
     for (int t = 0; t < kSmTaps; ++t)
@@ -369,18 +371,18 @@ conv_wgrad_small_kernel(Mri3dConvGeom g, const float* __restrict__ x, const floa
         const int oh = r % g.ho, od = r / g.ho;
         float gv[kSmCo];
         if (vec_dy) {
-            const float4* q = reinterpret_cast<const float4*>(dy + v * g.y_ld + co0);
-            const float4 a = q[0], b = q[1];
+            const T* q = dy + v * g.y_ld + co0;
+            const float4 a = ldf4(q), b = ldf4(q + 4);
             gv[0] = a.x, gv[1] = a.y, gv[2] = a.z, gv[3] = a.w, gv[4] = b.x, gv[5] = b.y, gv[6] = b.z, gv[7] = b.w;
         } else {
 #pragma unroll
-            for (int c = 0; c < kSmCo; ++c) gv[c] = (co0 + c < g.co) ? dy[v * g.y_ld + co0 + c] : 0.f;
+            for (int c = 0; c < kSmCo; ++c) gv[c] = (co0 + c < g.co) ? ldf(dy + v * g.y_ld + co0 + c) : 0.f;
         }
         if (cil == 0) {
 #pragma unroll
             for (int c = 0; c < kSmCo; ++c) bsum[c] += gv[c];
         }
-        const float* xn = x + (int64_t)n * g.di * g.hi * g.wi * g.x_ld + ci;
+        const T* xn = x + (int64_t)n * g.di * g.hi * g.wi * g.x_ld + ci;
 #pragma unroll
         for (int t = 0; t < kSmTaps; ++t) {
             if (t < taps) {
@@ -388,7 +390,7 @@ conv_wgrad_small_kernel(Mri3dConvGeom g, const float* __restrict__ x, const floa
                 const int id = od * g.sd - g.pd + kd * g.dd, ih = oh * g.sh - g.ph + kh * g.dh, iw = ow * g.sw - g.pw + kw * g.dw;
                 const bool ok = ci_ok && (unsigned)id < (unsigned)g.di && (unsigned)ih < (unsigned)g.hi &&
                                 (unsigned)iw < (unsigned)g.wi;
-                const float xv = ok ? xn[(((int64_t)id * g.hi + ih) * g.wi + iw) * g.x_ld] : 0.f;
+                const float xv = ok ? ldf(xn + (((int64_t)id * g.hi + ih) * g.wi + iw) * g.x_ld) : 0.f;
 #pragma unroll
                 for (int c = 0; c < kSmCo; ++c) acc[t][c] = fmaf(xv, gv[c], acc[t][c]);
             }
@@ -503,30 +505,32 @@ size_t conv_generic_workspace_bytes(const Mri3dConvGeom& g, int pass) {
     return a;
 }
 
-template <int T>
-static void launch_fwd(const Mri3dConvGeom& g, const float* x, const float* wp, const float* bias, float* y, int CoP,
+template <int TL>
+static void launch_fwd(const Mri3dConvGeom& g, const void* x, const float* wp, const float* bias, void* y, int CoP,
                        hipStream_t s) {
     int64_t nvox = (int64_t)g.n * g.dout * g.ho * g.wo;
-    dim3 grid((unsigned)std::min<int64_t>(cdiv64(nvox, 256), 8192), CoP / T);
-    bool vec = (g.ci % 4 == 0) && (g.x_ld % 4 == 0) && ((reinterpret_cast<uintptr_t>(x) & 15) == 0);
-    if (vec)
-        hipLaunchKernelGGL((conv_fwd_generic_kernel<T, true>), grid, dim3(256), 0, s, g, x, wp, bias, y, CoP);
-    else
-        hipLaunchKernelGGL((conv_fwd_generic_kernel<T, false>), grid, dim3(256), 0, s, g, x, wp, bias, y, CoP);
+    dim3 grid((unsigned)std::min<int64_t>(cdiv64(nvox, 256), 8192), CoP / TL);
+    bool vec = (g.ci % 4 == 0) && (g.x_ld % 4 == 0) && aligned_vec4(g.dtype, x);
+    MRI3D_DISPATCH_DTYPE(g.dtype, T, {
+        if (vec)
+            hipLaunchKernelGGL((conv_fwd_generic_kernel<T, TL, true>), grid, dim3(256), 0, s, g, (const T*)x, wp, bias, (T*)y, CoP);
+        else
+            hipLaunchKernelGGL((conv_fwd_generic_kernel<T, TL, false>), grid, dim3(256), 0, s, g, (const T*)x, wp, bias, (T*)y, CoP);
+    });
 }
 
-int conv_generic_fwd(const Mri3dConvGeom& g, const float* x, const float* w, const float* bias, float* y, void* ws,
+int conv_generic_fwd(const Mri3dConvGeom& g, const void* x, const float* w, const float* bias, void* y, void* ws,
                      size_t ws_bytes, hipStream_t s) {
     const int taps = g.kd * g.kh * g.kw;
-    const int T = pick_tile(g.co);
-    const int CoP = cdiv(g.co, T) * T;
+    const int TL = pick_tile(g.co);
+    const int CoP = cdiv(g.co, TL) * TL;
     size_t need = (size_t)taps * g.ci * CoP * sizeof(float);
     MRI3D_REQUIRE(ws != nullptr && ws_bytes >= need, MRI3D_EWORKSPACE, "conv3d_fwd: workspace %zu < %zu", ws_bytes, need);
     float* wp = static_cast<float*>(ws);
     int total = taps * g.ci * CoP;
     hipLaunchKernelGGL(repack_w_fwd_kernel, dim3(std::min(cdiv(total, 256), 1024)), dim3(256), 0, s, w, wp, g.co, g.ci,
                        taps, CoP);
-    switch (T) {
+    switch (TL) {
         case 16: launch_fwd<16>(g, x, wp, bias, y, CoP, s); break;
         case 8: launch_fwd<8>(g, x, wp, bias, y, CoP, s); break;
         case 4: launch_fwd<4>(g, x, wp, bias, y, CoP, s); break;
@@ -535,23 +539,25 @@ int conv_generic_fwd(const Mri3dConvGeom& g, const float* x, const float* w, con
     return check_launch("conv3d_fwd(generic)");
 }
 
-template <int T>
-static void launch_dgrad(const Mri3dConvGeom& g, const float* dy, const float* wp, const float* bias, float* dx,
+template <int TL>
+static void launch_dgrad(const Mri3dConvGeom& g, const void* dy, const float* wp, const float* bias, void* dx,
                          int CiP, hipStream_t s) {
     int64_t nvox = (int64_t)g.n * g.di * g.hi * g.wi;
-    dim3 grid((unsigned)std::min<int64_t>(cdiv64(nvox, 256), 8192), CiP / T);
-    bool vec = (g.co % 4 == 0) && (g.y_ld % 4 == 0) && ((reinterpret_cast<uintptr_t>(dy) & 15) == 0);
-    if (vec)
-        hipLaunchKernelGGL((conv_dgrad_generic_kernel<T, true>), grid, dim3(256), 0, s, g, dy, wp, bias, dx, CiP);
-    else
-        hipLaunchKernelGGL((conv_dgrad_generic_kernel<T, false>), grid, dim3(256), 0, s, g, dy, wp, bias, dx, CiP);
+    dim3 grid((unsigned)std::min<int64_t>(cdiv64(nvox, 256), 8192), CiP / TL);
+    bool vec = (g.co % 4 == 0) && (g.y_ld % 4 == 0) && aligned_vec4(g.dtype, dy);
+    MRI3D_DISPATCH_DTYPE(g.dtype, T, {
+        if (vec)
+            hipLaunchKernelGGL((conv_dgrad_generic_kernel<T, TL, true>), grid, dim3(256), 0, s, g, (const T*)dy, wp, bias, (T*)dx, CiP);
+        else
+            hipLaunchKernelGGL((conv_dgrad_generic_kernel<T, TL, false>), grid, dim3(256), 0, s, g, (const T*)dy, wp, bias, (T*)dx, CiP);
+    });
 }
 
-int conv_generic_dgrad(const Mri3dConvGeom& g, const float* dy, const float* w, const float* bias, float* dx, void* ws,
+int conv_generic_dgrad(const Mri3dConvGeom& g, const void* dy, const float* w, const float* bias, void* dx, void* ws,
                        size_t ws_bytes, hipStream_t s) {
     const int taps = g.kd * g.kh * g.kw;
-    const int T = pick_tile(g.ci);
-    const int CiP = cdiv(g.ci, T) * T;
+    const int TL = pick_tile(g.ci);
+    const int CiP = cdiv(g.ci, TL) * TL;
     size_t need = (size_t)taps * g.co * CiP * sizeof(float);
     MRI3D_REQUIRE(ws != nullptr && ws_bytes >= need, MRI3D_EWORKSPACE, "conv3d_dgrad: workspace %zu < %zu", ws_bytes,
                   need);
@@ -559,7 +565,7 @@ int conv_generic_dgrad(const Mri3dConvGeom& g, const float* dy, const float* w, 
     int total = taps * g.co * CiP;
     hipLaunchKernelGGL(repack_w_dgrad_kernel, dim3(std::min(cdiv(total, 256), 1024)), dim3(256), 0, s, w, wp, g.co,
                        g.ci, taps, CiP);
-    switch (T) {
+    switch (TL) {
         case 16: launch_dgrad<16>(g, dy, wp, bias, dx, CiP, s); break;
         case 8: launch_dgrad<8>(g, dy, wp, bias, dx, CiP, s); break;
         case 4: launch_dgrad<4>(g, dy, wp, bias, dx, CiP, s); break;
@@ -568,7 +574,7 @@ int conv_generic_dgrad(const Mri3dConvGeom& g, const float* dy, const float* w, 
     return check_launch("conv3d_dgrad(generic)");
 }
 
-int conv_generic_wgrad(const Mri3dConvGeom& g, const float* x, const float* dy, float* dw, float* dbias, void* ws,
+int conv_generic_wgrad(const Mri3dConvGeom& g, const void* x, const void* dy, float* dw, float* dbias, void* ws,
                        size_t ws_bytes, hipStream_t s) {
     if (wgrad_small_ok(g)) {
         WgradSmallPlan q = wgrad_small_plan(g);
@@ -578,8 +584,10 @@ int conv_generic_wgrad(const Mri3dConvGeom& g, const float* x, const float* dy, 
         float* bias_part = dbias ? part + q.part_floats : nullptr;
         const int taps = g.kd * g.kh * g.kw;
         // partial slots of padded channels are never written by the kernel and never read by the reduce
-        hipLaunchKernelGGL(conv_wgrad_small_kernel, dim3(q.gx, q.gy, q.gz), dim3(256), 0, s, g, x, dy, part, bias_part,
-                           q.CiL, q.CiP, q.CoP);
+        MRI3D_DISPATCH_DTYPE(g.dtype, T, {
+            hipLaunchKernelGGL(conv_wgrad_small_kernel<T>, dim3(q.gx, q.gy, q.gz), dim3(256), 0, s, g, (const T*)x,
+                               (const T*)dy, part, bias_part, q.CiL, q.CiP, q.CoP);
+        });
         const int total = g.co * g.ci * taps;
         hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(cdiv(total + g.co, 8)), dim3(256), 0, s, part, bias_part, dw,
                            dbias, q.gx, taps, g.ci, g.co, q.CiP, q.CoP);
@@ -593,11 +601,13 @@ int conv_generic_wgrad(const Mri3dConvGeom& g, const float* x, const float* dy, 
                   p.smem);
     float* part = static_cast<float*>(ws);
     float* bias_part = dbias ? part + p.part_floats : nullptr;
-    if (p.smem > 64 * 1024)
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_generic_kernel),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.smem);
-    hipLaunchKernelGGL(conv_wgrad_generic_kernel, dim3(p.gx, p.taps, p.gz), dim3(256), p.smem, s, g, x, dy, part,
-                       bias_part, p.Ci4, p.Co4, p.nitems, p.vsplit);
+    MRI3D_DISPATCH_DTYPE(g.dtype, T, {
+        if (p.smem > 64 * 1024)
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_generic_kernel<T>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.smem);
+        hipLaunchKernelGGL(conv_wgrad_generic_kernel<T>, dim3(p.gx, p.taps, p.gz), dim3(256), p.smem, s, g, (const T*)x,
+                           (const T*)dy, part, bias_part, p.Ci4, p.Co4, p.nitems, p.vsplit);
+    });
     int total = g.co * g.ci * p.taps;
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(cdiv(total + g.co, 8)), dim3(256), 0, s, part, bias_part, dw,
                        dbias, p.gx, p.taps, g.ci, g.co, p.Ci4 * 4, p.Co4 * 4);

@@ -499,14 +499,14 @@ static int run_mfma_fwd(const Mri3dConvGeom& g, bool dgrad, const float* in, con
     return check_launch(dgrad ? "conv3d_dgrad(mfma)" : "conv3d_fwd(mfma)");
 }
 
-int conv_mfma_fwd(const Mri3dConvGeom& g, const float* x, const float* w, const float* bias, float* y, void* ws,
+int conv_mfma_fwd(const Mri3dConvGeom& g, const void* x, const float* w, const float* bias, void* y, void* ws,
                   size_t ws_bytes, hipStream_t s) {
-    return run_mfma_fwd(g, false, x, w, bias, y, ws, ws_bytes, s);
+    return run_mfma_fwd(g, false, static_cast<const float*>(x), w, bias, static_cast<float*>(y), ws, ws_bytes, s);
 }
 
-int conv_mfma_dgrad(const Mri3dConvGeom& g, const float* dy, const float* w, const float* bias, float* dx, void* ws,
+int conv_mfma_dgrad(const Mri3dConvGeom& g, const void* dy, const float* w, const float* bias, void* dx, void* ws,
                     size_t ws_bytes, hipStream_t s) {
-    return run_mfma_fwd(g, true, dy, w, bias, dx, ws, ws_bytes, s);
+    return run_mfma_fwd(g, true, static_cast<const float*>(dy), w, bias, static_cast<float*>(dx), ws, ws_bytes, s);
 }
 
 // ================================================================== weight gradient
@@ -1053,7 +1053,9 @@ static bool mfma_wgrad_plan(const Mri3dConvGeom& g, MfmaWgradPlan& p) {
     return true;
 }
 
+// fp32 storage only: bf16 tensors take the kernels of conv_mfma_bf16.hip
 bool conv_mfma_supported(const Mri3dConvGeom& g, int pass) {
+    if (g.dtype != MRI3D_F32) return false;
     MfmaFwdPlan p;
     MfmaWgradPlan q;
     if (pass == MRI3D_PASS_FWD) return mfma_fwd_plan(g, false, p);
@@ -1091,8 +1093,10 @@ static void launch_mfma_wgrad(const MfmaWgradPlan& p, const Mri3dConvGeom& g, co
     }
 }
 
-int conv_mfma_wgrad(const Mri3dConvGeom& g, const float* x, const float* dy, float* dw, float* dbias, void* ws,
+int conv_mfma_wgrad(const Mri3dConvGeom& g, const void* xv, const void* dyv, float* dw, float* dbias, void* ws,
                     size_t ws_bytes, hipStream_t s) {
+    const float* x = static_cast<const float*>(xv);
+    const float* dy = static_cast<const float*>(dyv);
     MfmaWgradPlan p;
     MRI3D_REQUIRE(mfma_wgrad_plan(g, p), MRI3D_ENOTSUP, "conv3d_wgrad(mfma): unsupported geometry");
     MRI3D_REQUIRE(ws && ws_bytes >= p.part_floats * sizeof(float), MRI3D_EWORKSPACE,

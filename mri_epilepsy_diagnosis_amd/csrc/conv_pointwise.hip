@@ -12,10 +12,10 @@ namespace mri3d {
 
 // CO = compile-time bound on Co (weights of the lane's channel quad live in registers); QC = Ci/4 must divide 256 so
 // that a lane's quad never changes across the grid-stride loop; 4 independent voxels per iteration keep loads in flight.
-template <int CO>
+template <typename T, int CO>
 __global__ void __launch_bounds__(256)
-pw_dgrad_kernel(const float* __restrict__ dy, const float* __restrict__ w, const float* __restrict__ bias,
-                float* __restrict__ dx, int64_t nvox, int Ci, int Co, int x_ld, int y_ld) {
+pw_dgrad_kernel(const T* __restrict__ dy, const float* __restrict__ w, const float* __restrict__ bias,
+                T* __restrict__ dx, int64_t nvox, int Ci, int Co, int x_ld, int y_ld) {
     const int QC = Ci >> 2;
     const int q = threadIdx.x % QC, vl = threadIdx.x / QC, VL = 256 / QC;
     float4 wq[CO];
@@ -34,7 +34,7 @@ pw_dgrad_kernel(const float* __restrict__ dy, const float* __restrict__ w, const
         for (int u = 0; u < U; ++u) {
             const int64_t v = v0 + u * stride;
 #pragma unroll
-            for (int co = 0; co < CO; ++co) gv[u][co] = (v < nvox && co < Co) ? dy[v * y_ld + co] : 0.f;
+            for (int co = 0; co < CO; ++co) gv[u][co] = (v < nvox && co < Co) ? ldf(dy + v * y_ld + co) : 0.f;
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
@@ -48,7 +48,7 @@ pw_dgrad_kernel(const float* __restrict__ dy, const float* __restrict__ w, const
                 acc.z = fmaf(gv[u][co], wq[co].z, acc.z);
                 acc.w = fmaf(gv[u][co], wq[co].w, acc.w);
             }
-            *reinterpret_cast<float4*>(dx + v * x_ld + 4 * q) = acc;
+            stf4(dx + v * x_ld + 4 * q, acc);
         }
     }
 }
@@ -56,9 +56,9 @@ pw_dgrad_kernel(const float* __restrict__ dy, const float* __restrict__ w, const
 constexpr int kPwMaxBlocks = 1024;
 
 // part[blk][co][ci] (+ bias_part[blk][co])
-template <int CO>
+template <typename T, int CO>
 __global__ void __launch_bounds__(256)
-pw_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ dy, double* __restrict__ part,
+pw_wgrad_kernel(const T* __restrict__ x, const T* __restrict__ dy, double* __restrict__ part,
                 double* __restrict__ bias_part, int64_t nvox, int Ci, int Co, int x_ld, int y_ld) {
     extern __shared__ __attribute__((aligned(16))) double redd[];  // [256][4*CO + CO]
     const int QC = Ci >> 2;
@@ -82,9 +82,9 @@ pw_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ dy, doubl
             for (int u = 0; u < U; ++u) {   // issue all loads of the 4 voxels first
                 const int64_t v = v0 + u * stride;
                 const bool ok = v < nvox;
-                xv[u] = ok ? *reinterpret_cast<const float4*>(x + v * x_ld + 4 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
+                xv[u] = ok ? ldf4(x + v * x_ld + 4 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-                for (int c = 0; c < CO; ++c) gv[u][c] = (ok && c < Co) ? dy[v * y_ld + c] : 0.f;
+                for (int c = 0; c < CO; ++c) gv[u][c] = (ok && c < Co) ? ldf(dy + v * y_ld + c) : 0.f;
             }
 #pragma unroll
             for (int u = 0; u < U; ++u) {
@@ -168,42 +168,49 @@ size_t conv_pointwise_workspace_bytes(const Mri3dConvGeom& g, int pass) {
     return (size_t)pw_blocks(g) * (g.co * g.ci + g.co) * sizeof(double);
 }
 
-int conv_pointwise_dgrad(const Mri3dConvGeom& g, const float* dy, const float* w, const float* bias, float* dx,
+int conv_pointwise_dgrad(const Mri3dConvGeom& g, const void* dy, const float* w, const float* bias, void* dx,
                          hipStream_t s) {
-    MRI3D_REQUIRE((reinterpret_cast<uintptr_t>(dx) & 15) == 0, MRI3D_EINVAL,
-                  "conv3d_dgrad(pointwise): dx must be 16-byte aligned");
+    MRI3D_REQUIRE(aligned_vec4(g.dtype, dx), MRI3D_EINVAL, "conv3d_dgrad(pointwise): dx must be aligned to 4 elements");
     const int64_t nvox = (int64_t)g.n * g.di * g.hi * g.wi;
     const int VL = 256 / (g.ci >> 2);
     const unsigned grid = (unsigned)std::max<int64_t>(1, std::min<int64_t>(cdiv64(nvox, (int64_t)VL * 4), 2048));
-    if (g.co <= 2)
-        hipLaunchKernelGGL(pw_dgrad_kernel<2>, dim3(grid), dim3(256), 0, s, dy, w, bias, dx, nvox, g.ci, g.co, g.x_ld, g.y_ld);
-    else if (g.co <= 4)
-        hipLaunchKernelGGL(pw_dgrad_kernel<4>, dim3(grid), dim3(256), 0, s, dy, w, bias, dx, nvox, g.ci, g.co, g.x_ld, g.y_ld);
-    else
-        hipLaunchKernelGGL(pw_dgrad_kernel<8>, dim3(grid), dim3(256), 0, s, dy, w, bias, dx, nvox, g.ci, g.co, g.x_ld, g.y_ld);
+#define PW_DGRAD(CO)                                                                                                   \
+    hipLaunchKernelGGL((pw_dgrad_kernel<T, CO>), dim3(grid), dim3(256), 0, s, (const T*)dy, w, bias, (T*)dx, nvox, g.ci, g.co, \
+                       g.x_ld, g.y_ld)
+    MRI3D_DISPATCH_DTYPE(g.dtype, T, {
+        if (g.co <= 2) PW_DGRAD(2);
+        else if (g.co <= 4) PW_DGRAD(4);
+        else PW_DGRAD(8);
+    });
+#undef PW_DGRAD
     return check_launch("conv3d_dgrad(pointwise)");
 }
 
-int conv_pointwise_wgrad(const Mri3dConvGeom& g, const float* x, const float* dy, float* dw, float* dbias, void* ws,
+int conv_pointwise_wgrad(const Mri3dConvGeom& g, const void* x, const void* dy, float* dw, float* dbias, void* ws,
                          size_t ws_bytes, hipStream_t s) {
     const int nb = pw_blocks(g);
     const size_t need = conv_pointwise_workspace_bytes(g, MRI3D_PASS_WGRAD);
     MRI3D_REQUIRE(ws && ws_bytes >= need, MRI3D_EWORKSPACE, "conv3d_wgrad(pointwise): workspace %zu < %zu", ws_bytes, need);
-    MRI3D_REQUIRE((reinterpret_cast<uintptr_t>(x) & 15) == 0 && (reinterpret_cast<uintptr_t>(ws) & 7) == 0, MRI3D_EINVAL,
-                  "conv3d_wgrad(pointwise): x must be 16-byte aligned");
+    MRI3D_REQUIRE(aligned_vec4(g.dtype, x) && (reinterpret_cast<uintptr_t>(ws) & 7) == 0, MRI3D_EINVAL,
+                  "conv3d_wgrad(pointwise): x must be aligned to 4 elements");
     double* part = static_cast<double*>(ws);
     double* bias_part = dbias ? part + (size_t)nb * g.co * g.ci : nullptr;
     const int64_t nvox = (int64_t)g.n * g.di * g.hi * g.wi;
     const int CO = g.co <= 2 ? 2 : (g.co <= 4 ? 4 : 8);
     const size_t smem = (size_t)256 * 5 * CO * sizeof(double);
-    if (CO == 2)
-        hipLaunchKernelGGL(pw_wgrad_kernel<2>, dim3(nb), dim3(256), smem, s, x, dy, part, bias_part, nvox, g.ci, g.co, g.x_ld, g.y_ld);
-    else if (CO == 4)
-        hipLaunchKernelGGL(pw_wgrad_kernel<4>, dim3(nb), dim3(256), smem, s, x, dy, part, bias_part, nvox, g.ci, g.co, g.x_ld, g.y_ld);
-    else {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(pw_wgrad_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-        hipLaunchKernelGGL(pw_wgrad_kernel<8>, dim3(nb), dim3(256), smem, s, x, dy, part, bias_part, nvox, g.ci, g.co, g.x_ld, g.y_ld);
-    }
+#define PW_WGRAD(CO_)                                                                                                  \
+    do {                                                                                                               \
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(pw_wgrad_kernel<T, CO_>),                              \
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);                              \
+        hipLaunchKernelGGL((pw_wgrad_kernel<T, CO_>), dim3(nb), dim3(256), smem, s, (const T*)x, (const T*)dy, part,   \
+                           bias_part, nvox, g.ci, g.co, g.x_ld, g.y_ld);                                               \
+    } while (0)
+    MRI3D_DISPATCH_DTYPE(g.dtype, T, {
+        if (CO == 2) PW_WGRAD(2);
+        else if (CO == 4) PW_WGRAD(4);
+        else PW_WGRAD(8);
+    });
+#undef PW_WGRAD
     hipLaunchKernelGGL(pw_wgrad_reduce_kernel, dim3(cdiv(g.co * g.ci + g.co, 8)), dim3(256), 0, s, part, bias_part, dw, dbias,
                        nb, g.ci, g.co);
     return check_launch("conv3d_wgrad(pointwise)");

@@ -30,13 +30,13 @@ __device__ __forceinline__ void softmax_c(const float* z, float (&p)[C]) {
 }
 
 // part[n][blk][c][3] = (tp, sum_p, sum_g)
-template <int C>
+template <typename T, int C>
 __global__ void __launch_bounds__(256)
-dice_fwd_kernel(const float* __restrict__ logits, const float* __restrict__ target, double* __restrict__ part,
+dice_fwd_kernel(const T* __restrict__ logits, const float* __restrict__ target, double* __restrict__ part,
                 int64_t vox, int ct, int x_ld, int t_ld) {
     __shared__ double red[4][C * 3];
     const int n = blockIdx.y;
-    const float* zn = logits + (int64_t)n * vox * x_ld;
+    const T* zn = logits + (int64_t)n * vox * x_ld;
     const float* tn = target + (int64_t)n * vox * t_ld;
     double tp[C], sp[C], sg[C];  // torch's CPU reductions (the oracle's arithmetic) accumulate float sums in double
 #pragma unroll
@@ -44,7 +44,7 @@ dice_fwd_kernel(const float* __restrict__ logits, const float* __restrict__ targ
     for (int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; v < vox; v += (int64_t)gridDim.x * blockDim.x) {
         float z[C], p[C];
 #pragma unroll
-        for (int j = 0; j < C; ++j) z[j] = zn[v * x_ld + j];
+        for (int j = 0; j < C; ++j) z[j] = ldf(zn + v * x_ld + j);
         softmax_c<C>(z, p);
 #pragma unroll
         for (int j = 0; j < C; ++j) {
@@ -108,15 +108,15 @@ dice_finalize_kernel(const double* __restrict__ part, float* __restrict__ stats,
     if (threadIdx.x == 0) loss[0] = (float)(acc_loss / (double)(N * C));
 }
 
-template <int C>
+template <typename T, int C>
 __global__ void __launch_bounds__(256)
-dice_bwd_kernel(const float* __restrict__ logits, const float* __restrict__ target, const float* __restrict__ stats,
-                const float* __restrict__ dloss, float* __restrict__ dlogits, int64_t vox, int N, int ct, int x_ld,
+dice_bwd_kernel(const T* __restrict__ logits, const float* __restrict__ target, const float* __restrict__ stats,
+                const float* __restrict__ dloss, T* __restrict__ dlogits, int64_t vox, int N, int ct, int x_ld,
                 int t_ld, float eps) {
     const int n = blockIdx.y;
-    const float* zn = logits + (int64_t)n * vox * x_ld;
+    const T* zn = logits + (int64_t)n * vox * x_ld;
     const float* tn = target + (int64_t)n * vox * t_ld;
-    float* dn = dlogits + (int64_t)n * vox * x_ld;
+    T* dn = dlogits + (int64_t)n * vox * x_ld;
     // d(1 - dice)/dp_c(v) = -(2 g den - 2 tp)/den^2, scaled by dloss/(N*C)
     float ka[C], kb[C];
     const float scale = dloss[0] / (float)(N * C);
@@ -130,7 +130,7 @@ dice_bwd_kernel(const float* __restrict__ logits, const float* __restrict__ targ
     for (int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; v < vox; v += (int64_t)gridDim.x * blockDim.x) {
         float z[C], p[C], dp[C];
 #pragma unroll
-        for (int j = 0; j < C; ++j) z[j] = zn[v * x_ld + j];
+        for (int j = 0; j < C; ++j) z[j] = ldf(zn + v * x_ld + j);
         softmax_c<C>(z, p);
         float dot = 0.f;
 #pragma unroll
@@ -140,18 +140,19 @@ dice_bwd_kernel(const float* __restrict__ logits, const float* __restrict__ targ
             dot = fmaf(p[j], dp[j], dot);
         }
 #pragma unroll
-        for (int j = 0; j < C; ++j) dn[v * x_ld + j] = p[j] * (dp[j] - dot);
+        for (int j = 0; j < C; ++j) stf(dn + v * x_ld + j, p[j] * (dp[j] - dot));
     }
 }
 
+template <typename T>
 __global__ void __launch_bounds__(256)
-argmax_u8_kernel(const float* __restrict__ logits, uint8_t* __restrict__ out, int64_t nvox, int C, int ld) {
+argmax_u8_kernel(const T* __restrict__ logits, uint8_t* __restrict__ out, int64_t nvox, int C, int ld) {
     for (int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; v < nvox; v += (int64_t)gridDim.x * blockDim.x) {
-        const float* z = logits + v * ld;
-        float best = z[0];
+        const T* z = logits + v * ld;
+        float best = ldf(z);
         int bi = 0;
         for (int j = 1; j < C; ++j) {
-            float t = z[j];
+            float t = ldf(z + j);
             // torch.argmax: first maximal value; NaN counts as maximal
             if ((t > best && best == best) || (t != t && best == best)) { best = t; bi = j; }
         }
@@ -173,7 +174,7 @@ using namespace mri3d;
 
 static int dice_check(const Mri3dDiceGeom* g, const char* who) {
     MRI3D_REQUIRE(g != nullptr, MRI3D_EINVAL, "%s: null geometry", who);
-    MRI3D_REQUIRE(g->dtype == MRI3D_F32, MRI3D_ENOTSUP, "%s: only MRI3D_F32 is implemented", who);
+    MRI3D_REQUIRE(g->dtype == MRI3D_F32 || g->dtype == MRI3D_BF16, MRI3D_ENOTSUP, "%s: unknown dtype %d", who, g->dtype);
     MRI3D_REQUIRE(g->n > 0 && g->vox > 0, MRI3D_EINVAL, "%s: empty tensor", who);
     MRI3D_REQUIRE(g->c >= 2 && g->c <= kDiceMaxC, MRI3D_ENOTSUP, "%s: classes must be in [2,%d], got %d", who, kDiceMaxC,
                   g->c);
@@ -209,9 +210,9 @@ extern "C" int mri3d_softmax_dice_fwd(const Mri3dDiceGeom* g, const void* logits
     int nblk = dice_blocks(*g);
     double* part = static_cast<double*>(workspace);
 #define CALL(CC)                                                                                              \
-    hipLaunchKernelGGL(dice_fwd_kernel<CC>, dim3(nblk, g->n), dim3(256), 0, s, (const float*)logits,          \
+    hipLaunchKernelGGL((dice_fwd_kernel<T, CC>), dim3(nblk, g->n), dim3(256), 0, s, (const T*)logits,         \
                        (const float*)target, part, g->vox, g->ct, g->x_ld, g->t_ld)
-    DICE_DISPATCH(CALL)
+    MRI3D_DISPATCH_DTYPE(g->dtype, T, { DICE_DISPATCH(CALL) });
 #undef CALL
     hipLaunchKernelGGL(dice_finalize_kernel, dim3(1), dim3(256), 0, s, part, stats, loss, g->n, g->c, nblk, g->eps);
     return check_launch("softmax_dice_fwd");
@@ -226,20 +227,22 @@ extern "C" int mri3d_softmax_dice_bwd(const Mri3dDiceGeom* g, const void* logits
     int nblk = stream_grid(g->vox, 256);
     if (nblk * g->n > 4096) nblk = 4096 / g->n > 0 ? 4096 / g->n : 1;
 #define CALL(CC)                                                                                              \
-    hipLaunchKernelGGL(dice_bwd_kernel<CC>, dim3(nblk, g->n), dim3(256), 0, s, (const float*)logits,          \
-                       (const float*)target, stats, dloss, (float*)dlogits, g->vox, g->n, g->ct, g->x_ld,    \
+    hipLaunchKernelGGL((dice_bwd_kernel<T, CC>), dim3(nblk, g->n), dim3(256), 0, s, (const T*)logits,         \
+                       (const float*)target, stats, dloss, (T*)dlogits, g->vox, g->n, g->ct, g->x_ld,        \
                        g->t_ld, g->eps)
-    DICE_DISPATCH(CALL)
+    MRI3D_DISPATCH_DTYPE(g->dtype, T, { DICE_DISPATCH(CALL) });
 #undef CALL
     return check_launch("softmax_dice_bwd");
 }
 
 extern "C" int mri3d_argmax_u8(const void* logits, uint8_t* out, int64_t nvox, int32_t c, int32_t ld, int32_t dtype,
                                mri3d_stream_t stream) {
-    MRI3D_REQUIRE(dtype == MRI3D_F32, MRI3D_ENOTSUP, "argmax_u8: only MRI3D_F32 is implemented");
+    MRI3D_REQUIRE(dtype == MRI3D_F32 || dtype == MRI3D_BF16, MRI3D_ENOTSUP, "argmax_u8: unknown dtype %d", dtype);
     MRI3D_REQUIRE(logits && out && nvox > 0 && c > 0 && c <= 256 && ld >= c, MRI3D_EINVAL, "argmax_u8: bad arguments");
     hipStream_t s = static_cast<hipStream_t>(stream);
-    hipLaunchKernelGGL(argmax_u8_kernel, dim3(stream_grid(nvox, 256)), dim3(256), 0, s, (const float*)logits, out, nvox,
-                       c, ld);
+    MRI3D_DISPATCH_DTYPE(dtype, T, {
+        hipLaunchKernelGGL(argmax_u8_kernel<T>, dim3(stream_grid(nvox, 256)), dim3(256), 0, s, (const T*)logits, out, nvox, c,
+                           ld);
+    });
     return check_launch("argmax_u8");
 }

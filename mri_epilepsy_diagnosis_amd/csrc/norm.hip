@@ -28,10 +28,6 @@ struct NormPlan {
 constexpr int kNormMaxBlocks = 1024;  // 4 blocks/CU of streaming work; keeps the finalize pass short
 constexpr int kFinQL = 16;            // partial-sum lanes per channel in the finalize kernels
 
-static inline bool aligned16(const void* a, const void* b = nullptr, const void* c = nullptr) {
-    return ((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(b) | reinterpret_cast<uintptr_t>(c)) & 15) == 0;
-}
-
 static NormPlan norm_plan(const Mri3dNormGeom& g, bool al) {
     NormPlan p;
     p.vec = (g.c % 4 == 0 && g.x_ld % 4 == 0 && g.y_ld % 4 == 0 && al) ? 4 : 1;
@@ -59,35 +55,37 @@ size_t norm_workspace_floats(const Mri3dNormGeom& g) {
 
 template <int VEC>
 struct Ld {
-    static __device__ __forceinline__ void load(const float* p, float (&v)[VEC]) {
+    template <typename T>
+    static __device__ __forceinline__ void load(const T* p, float (&v)[VEC]) {
         if (VEC == 4) {
-            float4 t = *reinterpret_cast<const float4*>(p);
+            float4 t = ldf4(p);
             v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
         } else {
-            v[0] = *p;
+            v[0] = ldf(p);
         }
     }
-    static __device__ __forceinline__ void store(float* p, const float (&v)[VEC]) {
+    template <typename T>
+    static __device__ __forceinline__ void store(T* p, const float (&v)[VEC]) {
         if (VEC == 4) {
-            *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
+            stf4(p, make_float4(v[0], v[1], v[2], v[3]));
         } else {
-            *p = v[0];
+            stf(p, v[0]);
         }
     }
 };
 
 // ------------------------------------------------------------------ statistics
 // partial layout: part[((group*cy... flattened as [group][blk][c][2]
-template <int VEC>
+template <typename T, int VEC>
 __global__ void __launch_bounds__(256)
-norm_stats_kernel(const float* __restrict__ x, double* __restrict__ part, int C, int ld, int64_t gvox, int CL, int VT) {
+norm_stats_kernel(const T* __restrict__ x, double* __restrict__ part, int C, int ld, int64_t gvox, int CL, int VT) {
     __shared__ double red[256 * 2 * VEC];
     const int tid = threadIdx.x;
     const int cl = tid % CL, vt = tid / CL;
     const int c0 = (blockIdx.y * CL + cl) * VEC;
     const bool active = vt < VT && c0 < C;
     const int group = blockIdx.z;
-    const float* xg = x + (int64_t)group * gvox * ld;
+    const T* xg = x + (int64_t)group * gvox * ld;
     // double accumulators: torch's CPU batch-norm (the oracle's arithmetic) accumulates float sums in double
     double s[VEC], ss[VEC];
     float k[VEC];
@@ -124,8 +122,9 @@ norm_stats_kernel(const float* __restrict__ x, double* __restrict__ part, int C,
     }
 }
 
+template <typename T>
 __global__ void __launch_bounds__(256)
-norm_stats_finalize_kernel(const float* __restrict__ x, const double* __restrict__ part,
+norm_stats_finalize_kernel(const T* __restrict__ x, const double* __restrict__ part,
                            float* __restrict__ mean, float* __restrict__ invstd,
                            float* __restrict__ running_mean, float* __restrict__ running_var,
                            float momentum, float eps, int C, int ld, int64_t gvox, int nblk, int groups) {
@@ -170,7 +169,8 @@ norm_stats_finalize_kernel(const float* __restrict__ x, const double* __restrict
 
 // GroupNorm statistics: one thread per (n, group) pools the per-channel shifted moments of its group_c channels.
 //   per channel: s = sum(x - k), ss = sum((x - k)^2) with k = first voxel  =>  sum x = s + cnt*k, sum x^2 = ss + 2k*s + cnt*k^2
-__global__ void norm_stats_group_finalize_kernel(const float* __restrict__ x, const double* __restrict__ part,
+template <typename T>
+__global__ void norm_stats_group_finalize_kernel(const T* __restrict__ x, const double* __restrict__ part,
                                                  float* __restrict__ mean, float* __restrict__ invstd, float eps, int C,
                                                  int ld, int64_t gvox, int nblk, int groups, int group_c) {
     const int G = C / group_c;
@@ -222,9 +222,9 @@ __global__ void norm_act_bwd_group_combine_kernel(float* __restrict__ sums, cons
 }
 
 // ------------------------------------------------------------------ forward apply
-template <int VEC>
+template <typename T, int VEC>
 __global__ void __launch_bounds__(256)
-norm_act_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, const float* __restrict__ mean,
+norm_act_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, const float* __restrict__ mean,
                     const float* __restrict__ invstd, const float* __restrict__ gamma, const float* __restrict__ beta,
                     const float* __restrict__ alpha, int alpha_n, int act, float slope, int C, int x_ld, int y_ld,
                     int64_t gvox, int CL, int VT) {
@@ -245,8 +245,8 @@ norm_act_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, const fl
         sh[j] = bt - mu * sc[j];
         al[j] = (act == MRI3D_ACT_PRELU) ? alpha[alpha_n == 1 ? 0 : c] : slope;
     }
-    const float* xg = x + (int64_t)group * gvox * x_ld;
-    float* yg = y + (int64_t)group * gvox * y_ld;
+    const T* xg = x + (int64_t)group * gvox * x_ld;
+    T* yg = y + (int64_t)group * gvox * y_ld;
     for (int64_t v = (int64_t)blockIdx.x * VT + vt; v < gvox; v += (int64_t)gridDim.x * VT) {
         float xv[VEC], yv[VEC];
         Ld<VEC>::load(xg + v * x_ld + c0, xv);
@@ -258,9 +258,9 @@ norm_act_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, const fl
 
 // ------------------------------------------------------------------ backward: reductions
 // part[group][blk][c][3] = (sum du, sum du*xhat, sum dy*u*[u<=0])
-template <int VEC>
+template <typename T, int VEC>
 __global__ void __launch_bounds__(256)
-norm_act_bwd_reduce_kernel(const float* __restrict__ x, const float* __restrict__ dy, double* __restrict__ part,
+norm_act_bwd_reduce_kernel(const T* __restrict__ x, const T* __restrict__ dy, double* __restrict__ part,
                            const float* __restrict__ mean, const float* __restrict__ invstd,
                            const float* __restrict__ gamma, const float* __restrict__ beta,
                            const float* __restrict__ alpha, int alpha_n, int act, float slope, int C, int x_ld,
@@ -286,8 +286,8 @@ norm_act_bwd_reduce_kernel(const float* __restrict__ x, const float* __restrict_
             al[j] = (act == MRI3D_ACT_PRELU) ? alpha[alpha_n == 1 ? 0 : c]
                                               : (act == MRI3D_ACT_LEAKY ? slope : (act == MRI3D_ACT_RELU ? 0.f : 1.f));
         }
-        const float* xg = x + (int64_t)group * gvox * x_ld;
-        const float* dg = dy + (int64_t)group * gvox * y_ld;
+        const T* xg = x + (int64_t)group * gvox * x_ld;
+        const T* dg = dy + (int64_t)group * gvox * y_ld;
         for (int64_t v = (int64_t)blockIdx.x * VT + vt; v < gvox; v += (int64_t)gridDim.x * VT) {
             float xv[VEC], gv[VEC];
             Ld<VEC>::load(xg + v * x_ld + c0, xv);
@@ -391,9 +391,9 @@ __global__ void norm_act_bwd_params_kernel(const float* __restrict__ sums, float
 }
 
 // ------------------------------------------------------------------ backward: dx
-template <int VEC>
+template <typename T, int VEC>
 __global__ void __launch_bounds__(256)
-norm_act_bwd_apply_kernel(const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ dx,
+norm_act_bwd_apply_kernel(const T* __restrict__ x, const T* __restrict__ dy, T* __restrict__ dx,
                           const float* __restrict__ sums, const float* __restrict__ mean,
                           const float* __restrict__ invstd, const float* __restrict__ gamma,
                           const float* __restrict__ beta, const float* __restrict__ alpha, int alpha_n, int act,
@@ -427,9 +427,9 @@ norm_act_bwd_apply_kernel(const float* __restrict__ x, const float* __restrict__
             k2[j] = 0.f;
         }
     }
-    const float* xg = x + (int64_t)group * gvox * x_ld;
-    const float* dg = dy + (int64_t)group * gvox * y_ld;
-    float* og = dx + (int64_t)group * gvox * x_ld;
+    const T* xg = x + (int64_t)group * gvox * x_ld;
+    const T* dg = dy + (int64_t)group * gvox * y_ld;
+    T* og = dx + (int64_t)group * gvox * x_ld;
     for (int64_t v = (int64_t)blockIdx.x * VT + vt; v < gvox; v += (int64_t)gridDim.x * VT) {
         float xv[VEC], gv[VEC], ov[VEC];
         Ld<VEC>::load(xg + v * x_ld + c0, xv);
@@ -456,7 +456,7 @@ extern "C" size_t mri3d_norm_workspace_bytes(const Mri3dNormGeom* g) {
 
 static int norm_check(const Mri3dNormGeom* g, const char* who) {
     MRI3D_REQUIRE(g != nullptr, MRI3D_EINVAL, "%s: null geometry", who);
-    MRI3D_REQUIRE(g->dtype == MRI3D_F32, MRI3D_ENOTSUP, "%s: only MRI3D_F32 is implemented", who);
+    MRI3D_REQUIRE(g->dtype == MRI3D_F32 || g->dtype == MRI3D_BF16, MRI3D_ENOTSUP, "%s: unknown dtype %d", who, g->dtype);
     MRI3D_REQUIRE(g->n > 0 && g->vox > 0 && g->c > 0 && g->x_ld >= g->c && g->y_ld >= g->c, MRI3D_EINVAL,
                   "%s: bad geometry n=%d vox=%lld c=%d x_ld=%d y_ld=%d", who, g->n, (long long)g->vox, g->c, g->x_ld,
                   g->y_ld);
@@ -478,22 +478,24 @@ extern "C" int mri3d_norm_stats(const Mri3dNormGeom* g, const void* x, float* me
     hipStream_t s = static_cast<hipStream_t>(stream);
     Mri3dNormGeom gg = *g;
     gg.y_ld = gg.x_ld;
-    NormPlan p = norm_plan(gg, aligned16(x));
+    NormPlan p = norm_plan(gg, aligned_vec4(g->dtype, x));
     double* part = static_cast<double*>(workspace);
-    const float* xf = static_cast<const float*>(x);
     dim3 grid(p.nblk, p.cy, p.groups);
-    if (p.vec == 4)
-        hipLaunchKernelGGL(norm_stats_kernel<4>, grid, dim3(256), 0, s, xf, part, g->c, g->x_ld, p.gvox, p.CL, p.VT);
-    else
-        hipLaunchKernelGGL(norm_stats_kernel<1>, grid, dim3(256), 0, s, xf, part, g->c, g->x_ld, p.gvox, p.CL, p.VT);
-    int tot = p.groups * g->c;
-    hipLaunchKernelGGL(norm_stats_finalize_kernel, dim3(cdiv(tot, 256 / kFinQL)), dim3(256), 0, s, xf, part, mean, invstd,
-                       running_mean, running_var, momentum, g->eps, g->c, g->x_ld, p.gvox, p.nblk, p.groups);
-    if (g->group_c > 0) {
-        const int ng = p.groups * (g->c / g->group_c);
-        hipLaunchKernelGGL(norm_stats_group_finalize_kernel, dim3(cdiv(ng, 64)), dim3(64), 0, s, xf, part, mean, invstd,
-                           g->eps, g->c, g->x_ld, p.gvox, p.nblk, p.groups, g->group_c);
-    }
+    const int tot = p.groups * g->c;
+    MRI3D_DISPATCH_DTYPE(g->dtype, T, {
+        const T* xf = static_cast<const T*>(x);
+        if (p.vec == 4)
+            hipLaunchKernelGGL((norm_stats_kernel<T, 4>), grid, dim3(256), 0, s, xf, part, g->c, g->x_ld, p.gvox, p.CL, p.VT);
+        else
+            hipLaunchKernelGGL((norm_stats_kernel<T, 1>), grid, dim3(256), 0, s, xf, part, g->c, g->x_ld, p.gvox, p.CL, p.VT);
+        hipLaunchKernelGGL(norm_stats_finalize_kernel<T>, dim3(cdiv(tot, 256 / kFinQL)), dim3(256), 0, s, xf, part, mean,
+                           invstd, running_mean, running_var, momentum, g->eps, g->c, g->x_ld, p.gvox, p.nblk, p.groups);
+        if (g->group_c > 0) {
+            const int ng = p.groups * (g->c / g->group_c);
+            hipLaunchKernelGGL(norm_stats_group_finalize_kernel<T>, dim3(cdiv(ng, 64)), dim3(64), 0, s, xf, part, mean,
+                               invstd, g->eps, g->c, g->x_ld, p.gvox, p.nblk, p.groups, g->group_c);
+        }
+    });
     return check_launch("norm_stats");
 }
 
@@ -506,16 +508,18 @@ extern "C" int mri3d_norm_act_fwd(const Mri3dNormGeom* g, const void* x, const f
     MRI3D_REQUIRE((mean == nullptr) == (invstd == nullptr), MRI3D_EINVAL, "norm_act_fwd: mean/invstd must both be set");
     MRI3D_REQUIRE(g->act != MRI3D_ACT_PRELU || alpha, MRI3D_EINVAL, "norm_act_fwd: PReLU needs alpha");
     hipStream_t s = static_cast<hipStream_t>(stream);
-    NormPlan p = norm_plan(*g, aligned16(x, y));
+    NormPlan p = norm_plan(*g, aligned_vec4(g->dtype, x, y));
     dim3 grid(p.nblk, p.cy, p.groups);
-    const float* xf = static_cast<const float*>(x);
-    float* yf = static_cast<float*>(y);
-    if (p.vec == 4)
-        hipLaunchKernelGGL(norm_act_fwd_kernel<4>, grid, dim3(256), 0, s, xf, yf, mean, invstd, gamma, beta, alpha,
-                           g->alpha_n, g->act, g->slope, g->c, g->x_ld, g->y_ld, p.gvox, p.CL, p.VT);
-    else
-        hipLaunchKernelGGL(norm_act_fwd_kernel<1>, grid, dim3(256), 0, s, xf, yf, mean, invstd, gamma, beta, alpha,
-                           g->alpha_n, g->act, g->slope, g->c, g->x_ld, g->y_ld, p.gvox, p.CL, p.VT);
+    MRI3D_DISPATCH_DTYPE(g->dtype, T, {
+        const T* xf = static_cast<const T*>(x);
+        T* yf = static_cast<T*>(y);
+        if (p.vec == 4)
+            hipLaunchKernelGGL((norm_act_fwd_kernel<T, 4>), grid, dim3(256), 0, s, xf, yf, mean, invstd, gamma, beta, alpha,
+                               g->alpha_n, g->act, g->slope, g->c, g->x_ld, g->y_ld, p.gvox, p.CL, p.VT);
+        else
+            hipLaunchKernelGGL((norm_act_fwd_kernel<T, 1>), grid, dim3(256), 0, s, xf, yf, mean, invstd, gamma, beta, alpha,
+                               g->alpha_n, g->act, g->slope, g->c, g->x_ld, g->y_ld, p.gvox, p.CL, p.VT);
+    });
     return check_launch("norm_act_fwd");
 }
 
@@ -533,39 +537,43 @@ extern "C" int mri3d_norm_act_bwd(const Mri3dNormGeom* g, int training, const vo
                   "norm_act_bwd: workspace %zu < %zu", ws_bytes, mri3d_norm_workspace_bytes(g));
     hipStream_t s = static_cast<hipStream_t>(stream);
     // x/dx share pitch x_ld, dy has pitch y_ld
-    NormPlan p = norm_plan(*g, aligned16(x, dy, dx));
+    NormPlan p = norm_plan(*g, aligned_vec4(g->dtype, x, dy, dx));
     dim3 grid(p.nblk, p.cy, p.groups);
-    const float* xf = static_cast<const float*>(x);
-    const float* df = static_cast<const float*>(dy);
-    float* of = static_cast<float*>(dx);
     double* part = static_cast<double*>(workspace);
     float* sums = reinterpret_cast<float*>(part + (size_t)p.groups * p.nblk * g->c * 3);
     const bool need_reduce = training || dgamma || dbeta || dalpha;
-    if (need_reduce) {
-        if (p.vec == 4)
-            hipLaunchKernelGGL(norm_act_bwd_reduce_kernel<4>, grid, dim3(256), 0, s, xf, df, part, mean, invstd, gamma,
-                               beta, alpha, g->alpha_n, g->act, g->slope, g->c, g->x_ld, g->y_ld, p.gvox, p.CL, p.VT);
-        else
-            hipLaunchKernelGGL(norm_act_bwd_reduce_kernel<1>, grid, dim3(256), 0, s, xf, df, part, mean, invstd, gamma,
-                               beta, alpha, g->alpha_n, g->act, g->slope, g->c, g->x_ld, g->y_ld, p.gvox, p.CL, p.VT);
-        hipLaunchKernelGGL(norm_act_bwd_sums_kernel, dim3(cdiv(p.groups * g->c, 256 / kFinQL)), dim3(256), 0, s, part,
-                           sums, g->c, p.nblk, p.groups);
-        if (dgamma || dbeta || dalpha)
-            hipLaunchKernelGGL(norm_act_bwd_params_kernel, dim3(1), dim3(256), 0, s, sums, dgamma, dbeta, dalpha,
-                               g->alpha_n, g->c, p.groups);
-        if (g->group_c > 0 && training) {
-            const int ng = p.groups * (g->c / g->group_c);
-            hipLaunchKernelGGL(norm_act_bwd_group_combine_kernel, dim3(cdiv(ng, 64)), dim3(64), 0, s, sums, gamma, g->c,
-                               p.groups, g->group_c);
+    MRI3D_DISPATCH_DTYPE(g->dtype, T, {
+        const T* xf = static_cast<const T*>(x);
+        const T* df = static_cast<const T*>(dy);
+        T* of = static_cast<T*>(dx);
+        if (need_reduce) {
+            if (p.vec == 4)
+                hipLaunchKernelGGL((norm_act_bwd_reduce_kernel<T, 4>), grid, dim3(256), 0, s, xf, df, part, mean, invstd,
+                                   gamma, beta, alpha, g->alpha_n, g->act, g->slope, g->c, g->x_ld, g->y_ld, p.gvox, p.CL,
+                                   p.VT);
+            else
+                hipLaunchKernelGGL((norm_act_bwd_reduce_kernel<T, 1>), grid, dim3(256), 0, s, xf, df, part, mean, invstd,
+                                   gamma, beta, alpha, g->alpha_n, g->act, g->slope, g->c, g->x_ld, g->y_ld, p.gvox, p.CL,
+                                   p.VT);
+            hipLaunchKernelGGL(norm_act_bwd_sums_kernel, dim3(cdiv(p.groups * g->c, 256 / kFinQL)), dim3(256), 0, s, part,
+                               sums, g->c, p.nblk, p.groups);
+            if (dgamma || dbeta || dalpha)
+                hipLaunchKernelGGL(norm_act_bwd_params_kernel, dim3(1), dim3(256), 0, s, sums, dgamma, dbeta, dalpha,
+                                   g->alpha_n, g->c, p.groups);
+            if (g->group_c > 0 && training) {
+                const int ng = p.groups * (g->c / g->group_c);
+                hipLaunchKernelGGL(norm_act_bwd_group_combine_kernel, dim3(cdiv(ng, 64)), dim3(64), 0, s, sums, gamma,
+                                   g->c, p.groups, g->group_c);
+            }
         }
-    }
-    if (p.vec == 4)
-        hipLaunchKernelGGL(norm_act_bwd_apply_kernel<4>, grid, dim3(256), 0, s, xf, df, of, sums, mean, invstd, gamma,
-                           beta, alpha, g->alpha_n, g->act, g->slope, training, g->c, g->x_ld, g->y_ld, p.gvox, p.CL,
-                           p.VT, g->group_c);
-    else
-        hipLaunchKernelGGL(norm_act_bwd_apply_kernel<1>, grid, dim3(256), 0, s, xf, df, of, sums, mean, invstd, gamma,
-                           beta, alpha, g->alpha_n, g->act, g->slope, training, g->c, g->x_ld, g->y_ld, p.gvox, p.CL,
-                           p.VT, g->group_c);
+        if (p.vec == 4)
+            hipLaunchKernelGGL((norm_act_bwd_apply_kernel<T, 4>), grid, dim3(256), 0, s, xf, df, of, sums, mean, invstd,
+                               gamma, beta, alpha, g->alpha_n, g->act, g->slope, training, g->c, g->x_ld, g->y_ld, p.gvox,
+                               p.CL, p.VT, g->group_c);
+        else
+            hipLaunchKernelGGL((norm_act_bwd_apply_kernel<T, 1>), grid, dim3(256), 0, s, xf, df, of, sums, mean, invstd,
+                               gamma, beta, alpha, g->alpha_n, g->act, g->slope, training, g->c, g->x_ld, g->y_ld, p.gvox,
+                               p.CL, p.VT, g->group_c);
+    });
     return check_launch("norm_act_bwd");
 }

@@ -15,17 +15,19 @@ namespace mri3d {
 template <int VEC>
 struct V {
     float v[VEC];
-    __device__ __forceinline__ void load(const float* p) {
+    template <typename T>
+    __device__ __forceinline__ void load(const T* p) {
         if (VEC == 4) {
-            float4 t = *reinterpret_cast<const float4*>(p);
+            float4 t = ldf4(p);
             v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
         } else {
-            v[0] = *p;
+            v[0] = ldf(p);
         }
     }
-    __device__ __forceinline__ void store(float* p) const {
-        if (VEC == 4) *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
-        else *p = v[0];
+    template <typename T>
+    __device__ __forceinline__ void store(T* p) const {
+        if (VEC == 4) stf4(p, make_float4(v[0], v[1], v[2], v[3]));
+        else stf(p, v[0]);
     }
 };
 
@@ -34,9 +36,9 @@ struct V {
 // made the first version of these kernels VALU-bound at 1.3-2.2 TB/s.
 
 // ------------------------------------------------------------------ max pool forward
-template <int VEC>
+template <typename T, int VEC>
 __global__ void __launch_bounds__(256)
-maxpool_fwd_kernel(Mri3dPoolGeom g, const float* __restrict__ x, float* __restrict__ y, uint8_t* __restrict__ idx, int hch) {
+maxpool_fwd_kernel(Mri3dPoolGeom g, const T* __restrict__ x, T* __restrict__ y, uint8_t* __restrict__ idx, int hch) {
     const unsigned CV = g.c / VEC;
     const int hchunks = (g.ho + hch - 1) / hch;
     const int slabs = g.n * g.dout * hchunks;
@@ -45,7 +47,7 @@ maxpool_fwd_kernel(Mri3dPoolGeom g, const float* __restrict__ x, float* __restri
         const int n = nd / g.dout, od = nd - n * g.dout;
         const int h0 = hc * hch, hn = min(hch, g.ho - h0);
         const unsigned inner = (unsigned)hn * g.wo * CV;
-        const float* xn = x + (int64_t)n * g.di * g.hi * g.wi * g.x_ld;
+        const T* xn = x + (int64_t)n * g.di * g.hi * g.wi * g.x_ld;
         const int64_t obase = ((int64_t)nd * g.ho + h0) * g.wo;
         for (unsigned e = threadIdx.x; e < inner; e += blockDim.x) {
             const unsigned cv = e % CV, pix = e / CV;
@@ -96,10 +98,10 @@ maxpool_fwd_kernel(Mri3dPoolGeom g, const float* __restrict__ x, float* __restri
 }
 
 // ------------------------------------------------------------------ max pool backward (gather over covering windows)
-template <int VEC>
+template <typename T, int VEC>
 __global__ void __launch_bounds__(256)
-maxpool_bwd_kernel(Mri3dPoolGeom g, const float* __restrict__ dy, const uint8_t* __restrict__ idx,
-                   float* __restrict__ dx, int hch) {
+maxpool_bwd_kernel(Mri3dPoolGeom g, const T* __restrict__ dy, const uint8_t* __restrict__ idx,
+                   T* __restrict__ dx, int hch) {
     const unsigned CV = g.c / VEC;
     const int hchunks = (g.hi + hch - 1) / hch;
     const int slabs = g.n * g.di * hchunks;
@@ -173,9 +175,9 @@ __device__ __forceinline__ int near_src(int o, float r, int in_size) {
     return i < in_size - 1 ? i : in_size - 1;
 }
 
-template <int VEC>
+template <typename T, int VEC>
 __global__ void __launch_bounds__(256)
-upsample_fwd_kernel(Mri3dUpGeom g, const float* __restrict__ x, float* __restrict__ y, int hch) {
+upsample_fwd_kernel(Mri3dUpGeom g, const T* __restrict__ x, T* __restrict__ y, int hch) {
     const unsigned CV = g.c / VEC;
     const int hchunks = (g.ho + hch - 1) / hch;
     const int slabs = g.n * g.dout * hchunks;
@@ -184,7 +186,7 @@ upsample_fwd_kernel(Mri3dUpGeom g, const float* __restrict__ x, float* __restric
         const int n = nd / g.dout, od = nd - n * g.dout;
         const int h0 = hc * hch, hn = min(hch, g.ho - h0);
         const unsigned inner = (unsigned)hn * g.wo * CV;
-        const float* xn = x + (int64_t)n * g.di * g.hi * g.wi * g.x_ld;
+        const T* xn = x + (int64_t)n * g.di * g.hi * g.wi * g.x_ld;
         const int64_t obase = ((int64_t)nd * g.ho + h0) * g.wo;
         // depth taps are uniform over the slab
         int idn = 0;
@@ -194,7 +196,7 @@ upsample_fwd_kernel(Mri3dUpGeom g, const float* __restrict__ x, float* __restric
         for (unsigned e = threadIdx.x; e < inner; e += blockDim.x) {
             const unsigned cv = e % CV, pix = e / CV;
             const int ow = pix % g.wo, oh = h0 + pix / g.wo;
-            const float* xc = xn + cv * VEC;
+            const T* xc = xn + cv * VEC;
             V<VEC> o;
             if (g.mode == MRI3D_UP_NEAREST) {
                 const int ih = near_src(oh, g.rh, g.hi), iw = near_src(ow, g.rw, g.wi);
@@ -261,9 +263,9 @@ __device__ __forceinline__ float up_weight(int o, int i, float r, int in_size, i
     return (L.i0 == i ? L.l0 : 0.f) + (L.i1 == i ? L.l1 : 0.f);
 }
 
-template <int VEC>
+template <typename T, int VEC>
 __global__ void __launch_bounds__(256)
-upsample_bwd_kernel(Mri3dUpGeom g, const float* __restrict__ dy, float* __restrict__ dx, const int* __restrict__ tab, int hch) {
+upsample_bwd_kernel(Mri3dUpGeom g, const T* __restrict__ dy, T* __restrict__ dx, const int* __restrict__ tab, int hch) {
     const unsigned CV = g.c / VEC;
     const int* lo_d = tab; const int* hi_d = tab + g.di;
     const int* lo_h = tab + 2 * g.di; const int* hi_h = lo_h + g.hi;
@@ -276,7 +278,7 @@ upsample_bwd_kernel(Mri3dUpGeom g, const float* __restrict__ dy, float* __restri
         const int hh0 = hc * hch, hn = min(hch, g.hi - hh0);
         const unsigned inner = (unsigned)hn * g.wi * CV;
         const int d0 = lo_d[id], d1 = hi_d[id];
-        const float* dn = dy + (int64_t)n * g.dout * g.ho * g.wo * g.y_ld;
+        const T* dn = dy + (int64_t)n * g.dout * g.ho * g.wo * g.y_ld;
         const int64_t ibase = ((int64_t)nd * g.hi + hh0) * g.wi;
         for (unsigned e = threadIdx.x; e < inner; e += blockDim.x) {
             const unsigned cv = e % CV, pix = e / CV;
@@ -285,7 +287,7 @@ upsample_bwd_kernel(Mri3dUpGeom g, const float* __restrict__ dy, float* __restri
 #pragma unroll
             for (int j = 0; j < VEC; ++j) acc[j] = 0.f;
             const int h0 = lo_h[ih], h1 = hi_h[ih], w0 = lo_w[iw], w1 = hi_w[iw];
-            const float* dc = dn + cv * VEC;
+            const T* dc = dn + cv * VEC;
             for (int od = d0; od <= d1; ++od) {
                 const float wd = up_weight(od, id, g.rd, g.di, g.mode, g.align_corners);
                 if (wd == 0.f) continue;
@@ -318,9 +320,8 @@ static inline void slab_plan(int nd, int h, int w, int cv, int& hch, int& grid) 
     grid = (int)std::min<int64_t>(slabs, 8192);
 }
 
-static inline bool vec_ok(int c, int a_ld, int b_ld, const void* a, const void* b) {
-    return c % 4 == 0 && a_ld % 4 == 0 && b_ld % 4 == 0 &&
-           ((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(b)) & 15) == 0;
+static inline bool vec_ok(int dtype, int c, int a_ld, int b_ld, const void* a, const void* b) {
+    return c % 4 == 0 && a_ld % 4 == 0 && b_ld % 4 == 0 && aligned_vec4(dtype, a, b);
 }
 
 }  // namespace mri3d
@@ -329,7 +330,7 @@ using namespace mri3d;
 
 static int pool_check(const Mri3dPoolGeom* g, const char* who) {
     MRI3D_REQUIRE(g != nullptr, MRI3D_EINVAL, "%s: null geometry", who);
-    MRI3D_REQUIRE(g->dtype == MRI3D_F32, MRI3D_ENOTSUP, "%s: only MRI3D_F32 is implemented", who);
+    MRI3D_REQUIRE(g->dtype == MRI3D_F32 || g->dtype == MRI3D_BF16, MRI3D_ENOTSUP, "%s: unknown dtype %d", who, g->dtype);
     MRI3D_REQUIRE(g->n > 0 && g->c > 0 && g->di > 0 && g->hi > 0 && g->wi > 0 && g->dout > 0 && g->ho > 0 && g->wo > 0,
                   MRI3D_EINVAL, "%s: empty tensor", who);
     MRI3D_REQUIRE(g->kd * g->kh * g->kw <= 256 && g->kd > 0 && g->kh > 0 && g->kw > 0, MRI3D_ENOTSUP,
@@ -348,13 +349,15 @@ extern "C" int mri3d_maxpool3d_fwd(const Mri3dPoolGeom* g, const void* x, void* 
     if (rc) return rc;
     MRI3D_REQUIRE(x && y && idx, MRI3D_EINVAL, "maxpool3d_fwd: null pointer");
     hipStream_t s = static_cast<hipStream_t>(stream);
-    bool v4 = vec_ok(g->c, g->x_ld, g->y_ld, x, y) && (reinterpret_cast<uintptr_t>(idx) & 3) == 0;
+    bool v4 = vec_ok(g->dtype, g->c, g->x_ld, g->y_ld, x, y) && (reinterpret_cast<uintptr_t>(idx) & 3) == 0;
     int hch, grid;
     slab_plan(g->n * g->dout, g->ho, g->wo, g->c / (v4 ? 4 : 1), hch, grid);
-    if (v4)
-        hipLaunchKernelGGL(maxpool_fwd_kernel<4>, dim3(grid), dim3(256), 0, s, *g, (const float*)x, (float*)y, idx, hch);
-    else
-        hipLaunchKernelGGL(maxpool_fwd_kernel<1>, dim3(grid), dim3(256), 0, s, *g, (const float*)x, (float*)y, idx, hch);
+    MRI3D_DISPATCH_DTYPE(g->dtype, T, {
+        if (v4)
+            hipLaunchKernelGGL((maxpool_fwd_kernel<T, 4>), dim3(grid), dim3(256), 0, s, *g, (const T*)x, (T*)y, idx, hch);
+        else
+            hipLaunchKernelGGL((maxpool_fwd_kernel<T, 1>), dim3(grid), dim3(256), 0, s, *g, (const T*)x, (T*)y, idx, hch);
+    });
     return check_launch("maxpool3d_fwd");
 }
 
@@ -364,19 +367,21 @@ extern "C" int mri3d_maxpool3d_bwd(const Mri3dPoolGeom* g, const void* dy, const
     if (rc) return rc;
     MRI3D_REQUIRE(dy && dx && idx, MRI3D_EINVAL, "maxpool3d_bwd: null pointer");
     hipStream_t s = static_cast<hipStream_t>(stream);
-    bool v4 = vec_ok(g->c, g->x_ld, g->y_ld, dx, dy) && (reinterpret_cast<uintptr_t>(idx) & 3) == 0;
+    bool v4 = vec_ok(g->dtype, g->c, g->x_ld, g->y_ld, dx, dy) && (reinterpret_cast<uintptr_t>(idx) & 3) == 0;
     int hch, grid;
     slab_plan(g->n * g->di, g->hi, g->wi, g->c / (v4 ? 4 : 1), hch, grid);
-    if (v4)
-        hipLaunchKernelGGL(maxpool_bwd_kernel<4>, dim3(grid), dim3(256), 0, s, *g, (const float*)dy, idx, (float*)dx, hch);
-    else
-        hipLaunchKernelGGL(maxpool_bwd_kernel<1>, dim3(grid), dim3(256), 0, s, *g, (const float*)dy, idx, (float*)dx, hch);
+    MRI3D_DISPATCH_DTYPE(g->dtype, T, {
+        if (v4)
+            hipLaunchKernelGGL((maxpool_bwd_kernel<T, 4>), dim3(grid), dim3(256), 0, s, *g, (const T*)dy, idx, (T*)dx, hch);
+        else
+            hipLaunchKernelGGL((maxpool_bwd_kernel<T, 1>), dim3(grid), dim3(256), 0, s, *g, (const T*)dy, idx, (T*)dx, hch);
+    });
     return check_launch("maxpool3d_bwd");
 }
 
 static int up_check(const Mri3dUpGeom* g, const char* who) {
     MRI3D_REQUIRE(g != nullptr, MRI3D_EINVAL, "%s: null geometry", who);
-    MRI3D_REQUIRE(g->dtype == MRI3D_F32, MRI3D_ENOTSUP, "%s: only MRI3D_F32 is implemented", who);
+    MRI3D_REQUIRE(g->dtype == MRI3D_F32 || g->dtype == MRI3D_BF16, MRI3D_ENOTSUP, "%s: unknown dtype %d", who, g->dtype);
     MRI3D_REQUIRE(g->n > 0 && g->c > 0 && g->di > 0 && g->hi > 0 && g->wi > 0 && g->dout > 0 && g->ho > 0 && g->wo > 0,
                   MRI3D_EINVAL, "%s: empty tensor", who);
     MRI3D_REQUIRE(g->mode == MRI3D_UP_NEAREST || g->mode == MRI3D_UP_TRILINEAR, MRI3D_EINVAL, "%s: bad mode %d", who,
@@ -396,13 +401,15 @@ extern "C" int mri3d_upsample3d_fwd(const Mri3dUpGeom* g, const void* x, void* y
     if (rc) return rc;
     MRI3D_REQUIRE(x && y, MRI3D_EINVAL, "upsample3d_fwd: null pointer");
     hipStream_t s = static_cast<hipStream_t>(stream);
-    bool v4 = vec_ok(g->c, g->x_ld, g->y_ld, x, y);
+    bool v4 = vec_ok(g->dtype, g->c, g->x_ld, g->y_ld, x, y);
     int hch, grid;
     slab_plan(g->n * g->dout, g->ho, g->wo, g->c / (v4 ? 4 : 1), hch, grid);
-    if (v4)
-        hipLaunchKernelGGL(upsample_fwd_kernel<4>, dim3(grid), dim3(256), 0, s, *g, (const float*)x, (float*)y, hch);
-    else
-        hipLaunchKernelGGL(upsample_fwd_kernel<1>, dim3(grid), dim3(256), 0, s, *g, (const float*)x, (float*)y, hch);
+    MRI3D_DISPATCH_DTYPE(g->dtype, T, {
+        if (v4)
+            hipLaunchKernelGGL((upsample_fwd_kernel<T, 4>), dim3(grid), dim3(256), 0, s, *g, (const T*)x, (T*)y, hch);
+        else
+            hipLaunchKernelGGL((upsample_fwd_kernel<T, 1>), dim3(grid), dim3(256), 0, s, *g, (const T*)x, (T*)y, hch);
+    });
     return check_launch("upsample3d_fwd");
 }
 
@@ -416,12 +423,14 @@ extern "C" int mri3d_upsample3d_bwd(const Mri3dUpGeom* g, const void* dy, void* 
     hipStream_t s = static_cast<hipStream_t>(stream);
     int* tab = static_cast<int*>(workspace);
     hipLaunchKernelGGL(upsample_tables_kernel, dim3(3), dim3(256), 0, s, *g, tab);
-    bool v4 = vec_ok(g->c, g->x_ld, g->y_ld, dx, dy);
+    bool v4 = vec_ok(g->dtype, g->c, g->x_ld, g->y_ld, dx, dy);
     int hch, grid;
     slab_plan(g->n * g->di, g->hi, g->wi, g->c / (v4 ? 4 : 1), hch, grid);
-    if (v4)
-        hipLaunchKernelGGL(upsample_bwd_kernel<4>, dim3(grid), dim3(256), 0, s, *g, (const float*)dy, (float*)dx, tab, hch);
-    else
-        hipLaunchKernelGGL(upsample_bwd_kernel<1>, dim3(grid), dim3(256), 0, s, *g, (const float*)dy, (float*)dx, tab, hch);
+    MRI3D_DISPATCH_DTYPE(g->dtype, T, {
+        if (v4)
+            hipLaunchKernelGGL((upsample_bwd_kernel<T, 4>), dim3(grid), dim3(256), 0, s, *g, (const T*)dy, (T*)dx, tab, hch);
+        else
+            hipLaunchKernelGGL((upsample_bwd_kernel<T, 1>), dim3(grid), dim3(256), 0, s, *g, (const T*)dy, (T*)dx, tab, hch);
+    });
     return check_launch("upsample3d_bwd");
 }

@@ -19,7 +19,7 @@ import math
 import torch
 
 from . import _lib
-from ._lib import (ACT_LEAKY, ACT_NONE, ACT_PRELU, ACT_RELU, F32, PASS_DGRAD, PASS_FWD, PASS_WGRAD, UP_NEAREST,
+from ._lib import (ACT_LEAKY, ACT_NONE, ACT_PRELU, ACT_RELU, BF16, F32, PASS_DGRAD, PASS_FWD, PASS_WGRAD, UP_NEAREST,
                    UP_TRILINEAR, ConvGeom, DiceGeom, NormGeom, PoolGeom, UpGeom, check)
 
 CL3D = torch.channels_last_3d
@@ -28,6 +28,7 @@ CL3D = torch.channels_last_3d
 
 
 def _require_device(*ts):
+    """Activation tensors: float32 or bfloat16 on a ROCm device."""
     for t in ts:
         if t is None:
             continue
@@ -35,8 +36,83 @@ def _require_device(*ts):
             raise RuntimeError(
                 "mri_epilepsy_diagnosis_amd ops run only on a ROCm device tensor (got %s); there is no CPU fallback"
                 % t.device)
+        if t.dtype not in (torch.float32, torch.bfloat16):
+            raise RuntimeError("mri_epilepsy_diagnosis_amd ops: only float32 / bfloat16 tensors are supported, got %s"
+                               % t.dtype)
+
+
+def _require_param(*ts):
+    """Parameters, statistics and targets: float32 on a ROCm device (bf16 regions keep fp32 master parameters)."""
+    for t in ts:
+        if t is None:
+            continue
+        _require_device(t)
         if t.dtype != torch.float32:
-            raise RuntimeError("mri_epilepsy_diagnosis_amd ops: only float32 tensors are supported, got %s" % t.dtype)
+            raise RuntimeError("mri_epilepsy_diagnosis_amd ops: parameters must be float32, got %s" % t.dtype)
+
+
+def _dt(t):
+    return BF16 if t.dtype == torch.bfloat16 else F32
+
+
+def _esz(t):
+    return 2.0 if t.dtype == torch.bfloat16 else 4.0
+
+
+# ----------------------------------------------------------------------------------------------- bf16 region
+# BASELINE configs[3] ("3D U-Net bf16"): inside `with autocast():` every conv stores its output in bfloat16 (fp32
+# accumulate), and all downstream volumetric ops follow the dtype of their input; parameters, statistics, parameter
+# gradients and the loss stay fp32 (the reference itself is fp32-only, so the region is opt-in like torch.autocast).
+_autocast_dtype = None
+
+
+class autocast:
+    def __init__(self, enabled=True, dtype=torch.bfloat16):
+        if dtype is not torch.bfloat16:
+            raise RuntimeError("mri_epilepsy_diagnosis_amd.autocast: only torch.bfloat16 is supported")
+        self.new = dtype if enabled else None
+
+    def __enter__(self):
+        global _autocast_dtype
+        self.prev = _autocast_dtype
+        _autocast_dtype = self.new
+        return self
+
+    def __exit__(self, *exc):
+        global _autocast_dtype
+        _autocast_dtype = self.prev
+        return False
+
+
+def convert(x, dtype):
+    """x.to(dtype) for NDHWC activations (fp32 <-> bf16, round-to-nearest-even) as a HIP pass; differentiable."""
+    return _ConvertFn.apply(x, dtype)
+
+
+def _convert_raw(x, dtype):
+    L = _lib.lib()
+    x, x_ld = _nd(x)
+    n, c, d, h, w = x.shape
+    y = torch.empty(x.shape, dtype=dtype, device=x.device, memory_format=CL3D)
+    check(L.mri3d_convert_channels(_ptr(x), _dt(x), _ptr(y), _dt(y), n * d * h * w, c, x_ld, c, _stream()),
+          "convert_channels")
+    return y
+
+
+class _ConvertFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, dtype):
+        _require_device(x)
+        ctx.src_dtype = x.dtype
+        if x.dtype == dtype:
+            return x.view_as(x)
+        return _convert_raw(x, dtype)
+
+    @staticmethod
+    def backward(ctx, dy):
+        if dy.dtype == ctx.src_dtype:
+            return dy, None
+        return _convert_raw(dy, ctx.src_dtype), None
 
 
 def _is_ndhwc_dense(x):
@@ -166,14 +242,16 @@ class _timed:
 
 
 def _conv_tag(kind, g):
-    return "conv3d_%s %dx%dx%d s%d d%d %d->%d @%dx%dx%d n%d" % (kind, g.kd, g.kh, g.kw, g.sd * g.sh * g.sw,
-                                                             g.dd * g.dh * g.dw, g.ci, g.co, g.dout, g.ho, g.wo, g.n)
+    return "conv3d_%s %dx%dx%d s%d d%d %d->%d @%dx%dx%d n%d%s" % (kind, g.kd, g.kh, g.kw, g.sd * g.sh * g.sw,
+                                                               g.dd * g.dh * g.dw, g.ci, g.co, g.dout, g.ho, g.wo, g.n,
+                                                               " bf16" if g.dtype == BF16 else "")
 
 
 def _conv_work(g, kind):
     flops = 2.0 * g.n * g.co * g.ci * g.kd * g.kh * g.kw * g.dout * g.ho * g.wo
-    xin = 4.0 * g.n * g.di * g.hi * g.wi * g.ci
-    yout = 4.0 * g.n * g.dout * g.ho * g.wo * g.co
+    esz = 2.0 if g.dtype == BF16 else 4.0
+    xin = esz * g.n * g.di * g.hi * g.wi * g.ci
+    yout = esz * g.n * g.dout * g.ho * g.wo * g.co
     wts = 4.0 * g.co * g.ci * g.kd * g.kh * g.kw
     return {"flops": flops, "bytes": xin + yout + wts}
 
@@ -189,7 +267,7 @@ def _triple(v):
 # ----------------------------------------------------------------------------------------------- conv
 
 
-def _conv_geom(xshape, wshape, stride, padding, dilation, x_ld=None, y_ld=None):
+def _conv_geom(xshape, wshape, stride, padding, dilation, x_ld=None, y_ld=None, dtype=F32):
     n, ci, di, hi, wi = xshape
     co, ci_w, kd, kh, kw = wshape
     if ci_w != ci:
@@ -203,7 +281,7 @@ def _conv_geom(xshape, wshape, stride, padding, dilation, x_ld=None, y_ld=None):
     if do <= 0 or ho <= 0 or wo <= 0:
         raise RuntimeError("Kernel size can't be greater than actual input size")
     return ConvGeom(n, di, hi, wi, ci, do, ho, wo, co, kd, kh, kw, sd, sh, sw, pd, ph, pw, dd, dh, dw,
-                    ci if x_ld is None else x_ld, co if y_ld is None else y_ld, F32)
+                    ci if x_ld is None else x_ld, co if y_ld is None else y_ld, dtype)
 
 
 def _conv_fwd(g, x, w, b):
@@ -243,10 +321,11 @@ def _conv_wgrad(g, x, dy, w_like, want_bias):
 class _Conv3dFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias, stride, padding, dilation):
-        _require_device(x, weight, bias)
+        _require_device(x)
+        _require_param(weight, bias)
         x, x_ld = _nd(x)
         w = weight.contiguous()
-        g = _conv_geom(x.shape, w.shape, stride, padding, dilation, x_ld=x_ld)
+        g = _conv_geom(x.shape, w.shape, stride, padding, dilation, x_ld=x_ld, dtype=_dt(x))
         y = _conv_fwd(g, x, w, bias)
         ctx.save_for_backward(x, w)
         ctx.geom = g
@@ -260,16 +339,19 @@ class _Conv3dFn(torch.autograd.Function):
         dy, y_ld = _nd(dy)
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
-            gd = _conv_geom(x.shape, w.shape, (g.sd, g.sh, g.sw), (g.pd, g.ph, g.pw), (g.dd, g.dh, g.dw), y_ld=y_ld)
+            gd = _conv_geom(x.shape, w.shape, (g.sd, g.sh, g.sw), (g.pd, g.ph, g.pw), (g.dd, g.dh, g.dw), y_ld=y_ld,
+                            dtype=g.dtype)
             dx = _conv_dgrad(gd, dy, w, None, x)       # dx is a fresh dense tensor (pitch = Cin)
         if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
             gw = _conv_geom(x.shape, w.shape, (g.sd, g.sh, g.sw), (g.pd, g.ph, g.pw), (g.dd, g.dh, g.dw), x_ld=g.x_ld,
-                            y_ld=y_ld)
+                            y_ld=y_ld, dtype=g.dtype)
             dw, db = _conv_wgrad(gw, x, dy, w, ctx.has_bias)
         return dx, dw, db, None, None, None
 
 
 def conv3d(x, weight, bias=None, stride=1, padding=0, dilation=1):
+    if _autocast_dtype is not None and x.dtype != _autocast_dtype:
+        x = convert(x, _autocast_dtype)
     return _Conv3dFn.apply(x, weight, bias, _triple(stride), _triple(padding), _triple(dilation))
 
 
@@ -277,7 +359,7 @@ def _channel_sum(t):
     """sum over (N,D,H,W) per channel with the norm-statistics kernel (mean * count)."""
     L = _lib.lib()
     n, c, d, h, w = t.shape
-    g = NormGeom(n, d * h * w, c, c, c, 0, ACT_NONE, 1, 0.0, 0.0, 0, F32)
+    g = NormGeom(n, d * h * w, c, c, c, 0, ACT_NONE, 1, 0.0, 0.0, 0, _dt(t))
     mean = torch.empty(c, dtype=torch.float32, device=t.device)
     invstd = torch.empty(c, dtype=torch.float32, device=t.device)
     ws = _workspace(L.mri3d_norm_workspace_bytes(ctypes.byref(g)), t.device)
@@ -291,7 +373,8 @@ class _ConvTranspose3dFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, weight, bias, stride, padding, output_padding, dilation):
-        _require_device(x, weight, bias)
+        _require_device(x)
+        _require_param(weight, bias)
         x = _cl(x)
         w = weight.contiguous()  # (Cin_t, Cout_t, kd, kh, kw) == conv weight (Co=Cin_t, Ci=Cout_t)
         n, cin_t, di, hi, wi = x.shape
@@ -302,7 +385,7 @@ class _ConvTranspose3dFn(torch.autograd.Function):
         oh = (hi - 1) * stride[1] - 2 * padding[1] + dilation[1] * (kh - 1) + output_padding[1] + 1
         ow = (wi - 1) * stride[2] - 2 * padding[2] + dilation[2] * (kw - 1) + output_padding[2] + 1
         # mirrored conv: input (n, cout_t, od, oh, ow) -> output (n, cin_t, di, hi, wi)
-        g = _conv_geom((n, cout_t, od, oh, ow), w.shape, stride, padding, dilation)
+        g = _conv_geom((n, cout_t, od, oh, ow), w.shape, stride, padding, dilation, dtype=_dt(x))
         if (g.dout, g.ho, g.wo) != (di, hi, wi):
             raise RuntimeError("conv_transpose3d: inconsistent output_padding")
         y = _conv_dgrad(g, x, w, bias, x)
@@ -327,6 +410,8 @@ class _ConvTranspose3dFn(torch.autograd.Function):
 
 
 def conv_transpose3d(x, weight, bias=None, stride=1, padding=0, output_padding=0, dilation=1):
+    if _autocast_dtype is not None and x.dtype != _autocast_dtype:
+        x = convert(x, _autocast_dtype)
     return _ConvTranspose3dFn.apply(x, weight, bias, _triple(stride), _triple(padding), _triple(output_padding),
                                     _triple(dilation))
 
@@ -343,7 +428,8 @@ class _NormActFn(torch.autograd.Function):
     def forward(ctx, x, gamma, beta, alpha, running_mean, running_var, stats_mode, momentum, eps, act, slope, out, group_c=0):
         # stats_mode: "batch" (compute + update running), "instance", "running" (eval BN), "none" (activation only)
         # out: None, or (buffer, channel_offset): write y into that channel slice of a wider NDHWC buffer
-        _require_device(x, gamma, beta, alpha)
+        _require_device(x)
+        _require_param(gamma, beta, alpha)
         L = _lib.lib()
         x, x_ld = _nd(x)
         n, c, d, h, w = x.shape
@@ -358,11 +444,12 @@ class _NormActFn(torch.autograd.Function):
         else:
             buf, y_off = out
             y_ld = _pitch_of(buf)
-            if y_ld != buf.shape[1] or tuple(buf.shape[2:]) != (d, h, w) or buf.shape[0] != n or y_off + c > buf.shape[1]:
+            if (y_ld != buf.shape[1] or tuple(buf.shape[2:]) != (d, h, w) or buf.shape[0] != n or y_off + c > buf.shape[1]
+                    or buf.dtype != x.dtype):
                 raise RuntimeError("norm_act(out=): buffer %s cannot hold a %s slice at channel %d"
                                    % (tuple(buf.shape), tuple(x.shape), y_off))
             y = _slice_view(buf, y_off, c)
-        g = NormGeom(n, d * h * w, c, x_ld, y_ld, instance, act_code, alpha_n, float(slope), float(eps), group_c, F32)
+        g = NormGeom(n, d * h * w, c, x_ld, y_ld, instance, act_code, alpha_n, float(slope), float(eps), group_c, _dt(x))
         mean = invstd = None
         if stats_mode in ("batch", "instance", "group"):
             groups = n if instance else 1
@@ -370,14 +457,14 @@ class _NormActFn(torch.autograd.Function):
             invstd = torch.empty(groups * c, dtype=torch.float32, device=x.device)
             ws = _workspace(L.mri3d_norm_workspace_bytes(ctypes.byref(g)), x.device)
             upd = stats_mode == "batch" and running_mean is not None
-            with _timed("norm_stats c%d vox%d n%d" % (c, g.vox, n), {"flops": 0.0, "bytes": 4.0 * x.numel()}):
+            with _timed("norm_stats c%d vox%d n%d" % (c, g.vox, n), {"flops": 0.0, "bytes": _esz(x) * x.numel()}):
                 check(L.mri3d_norm_stats(ctypes.byref(g), _ptr(x), _ptr(mean), _ptr(invstd),
                                          _ptr(running_mean) if upd else None, _ptr(running_var) if upd else None,
                                          float(momentum), _ptr(ws), ws.numel(), _stream()), "norm_stats")
         elif stats_mode == "running":
             mean = running_mean.detach().to(torch.float32).contiguous()
             invstd = torch.rsqrt(running_var.detach().to(torch.float32) + eps).contiguous()
-        with _timed("norm_act_fwd c%d vox%d n%d" % (c, g.vox, n), {"flops": 0.0, "bytes": 8.0 * x.numel()}):
+        with _timed("norm_act_fwd c%d vox%d n%d" % (c, g.vox, n), {"flops": 0.0, "bytes": 2 * _esz(x) * x.numel()}):
             check(L.mri3d_norm_act_fwd(ctypes.byref(g), _ptr(x), _ptr(mean), _ptr(invstd), _ptr(gamma), _ptr(beta),
                                        _ptr(alpha) if act_code == ACT_PRELU else None, _ptr(y), _stream()),
                   "norm_act_fwd")
@@ -396,13 +483,15 @@ class _NormActFn(torch.autograd.Function):
         if dx is None:  # dx shares x's pitch in the kernel: give it a dense x instead
             x = x.contiguous(memory_format=CL3D)
             dx = _new(x.shape, x)
-        g = NormGeom(g0.n, g0.vox, g0.c, g0.c, dy_ld, g0.instance, g0.act, g0.alpha_n, g0.slope, g0.eps, g0.group_c, F32)
+        if dy.dtype != x.dtype:
+            raise RuntimeError("norm_act backward: gradient dtype %s does not match activation dtype %s" % (dy.dtype, x.dtype))
+        g = NormGeom(g0.n, g0.vox, g0.c, g0.c, dy_ld, g0.instance, g0.act, g0.alpha_n, g0.slope, g0.eps, g0.group_c, g0.dtype)
         dgamma = torch.empty_like(gamma) if (gamma is not None and ctx.needs_input_grad[1]) else None
         dbeta = torch.empty_like(beta) if (beta is not None and ctx.needs_input_grad[2]) else None
         prelu = g.act == ACT_PRELU
         dalpha = torch.empty_like(alpha) if (prelu and ctx.needs_input_grad[3]) else None
         ws = _workspace(L.mri3d_norm_workspace_bytes(ctypes.byref(g)), x.device)
-        with _timed("norm_act_bwd c%d vox%d n%d" % (g.c, g.vox, g.n), {"flops": 0.0, "bytes": 20.0 * x.numel()}):
+        with _timed("norm_act_bwd c%d vox%d n%d" % (g.c, g.vox, g.n), {"flops": 0.0, "bytes": 5 * _esz(x) * x.numel()}):
             check(L.mri3d_norm_act_bwd(ctypes.byref(g), 1 if ctx.training_stats else 0, _ptr(x), _ptr(dy), _ptr(mean),
                                        _ptr(invstd), _ptr(gamma), _ptr(beta), _ptr(alpha) if prelu else None, _ptr(dx),
                                        _ptr(dgamma), _ptr(dbeta), _ptr(dalpha), _ptr(ws), ws.numel(), _stream()),
@@ -427,11 +516,12 @@ class _ScaleInstanceFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, scale):
-        _require_device(x, scale)
+        _require_device(x)
+        _require_param(scale)
         L = _lib.lib()
         x = _cl(x)
         n, c, d, h, w = x.shape
-        g = NormGeom(n, d * h * w, c, c, c, 1, ACT_NONE, 1, 0.0, 0.0, 0, F32)
+        g = NormGeom(n, d * h * w, c, c, c, 1, ACT_NONE, 1, 0.0, 0.0, 0, _dt(x))
         scale = scale.reshape(n * c).contiguous()
         zeros = torch.zeros_like(scale)
         y = _new(x.shape, x)
@@ -484,10 +574,10 @@ class _MaxPool3dFn(torch.autograd.Function):
         do, ho, wo = (_pool_out(i, k, s, p, False) for i, k, s, p in zip((d, h, w), kernel, stride, padding))
         if do <= 0 or ho <= 0 or wo <= 0:
             raise RuntimeError("max_pool3d: output size is too small (input %s, kernel %s)" % ((d, h, w), kernel))
-        g = PoolGeom(n, d, h, w, do, ho, wo, c, *kernel, *stride, *padding, x_ld, c, F32)
+        g = PoolGeom(n, d, h, w, do, ho, wo, c, *kernel, *stride, *padding, x_ld, c, _dt(x))
         y = _new((n, c, do, ho, wo), x)
         idx = torch.empty(n * do * ho * wo * c, dtype=torch.uint8, device=x.device)
-        with _timed("maxpool_fwd c%d" % c, {"flops": 0.0, "bytes": 4.0 * x.numel() + 5.0 * y.numel()}):
+        with _timed("maxpool_fwd c%d" % c, {"flops": 0.0, "bytes": _esz(x) * x.numel() + (_esz(x) + 1) * y.numel()}):
             check(L.mri3d_maxpool3d_fwd(ctypes.byref(g), _ptr(x), _ptr(y), _ptr(idx), _stream()), "maxpool3d_fwd")
         ctx.save_for_backward(idx)
         ctx.geom = g
@@ -502,8 +592,8 @@ class _MaxPool3dFn(torch.autograd.Function):
         dx = _new(ctx.xshape, dy)
         g0 = ctx.geom
         g = PoolGeom(g0.n, g0.di, g0.hi, g0.wi, g0.dout, g0.ho, g0.wo, g0.c, g0.kd, g0.kh, g0.kw, g0.sd, g0.sh, g0.sw,
-                     g0.pd, g0.ph, g0.pw, g0.c, dy_ld, F32)
-        with _timed("maxpool_bwd c%d" % g.c, {"flops": 0.0, "bytes": 4.0 * dx.numel() + 5.0 * dy.numel()}):
+                     g0.pd, g0.ph, g0.pw, g0.c, dy_ld, _dt(dy))
+        with _timed("maxpool_bwd c%d" % g.c, {"flops": 0.0, "bytes": _esz(dy) * dx.numel() + (_esz(dy) + 1) * dy.numel()}):
             check(L.mri3d_maxpool3d_bwd(ctypes.byref(g), _ptr(dy), _ptr(idx), _ptr(dx), _stream()), "maxpool3d_bwd")
         return dx, None, None, None
 
@@ -530,13 +620,14 @@ class _Upsample3dFn(torch.autograd.Function):
         else:
             buf, y_off = out
             y_ld = _pitch_of(buf)
-            if y_ld != buf.shape[1] or tuple(buf.shape[2:]) != (do, ho, wo) or buf.shape[0] != n or y_off + c > buf.shape[1]:
+            if (y_ld != buf.shape[1] or tuple(buf.shape[2:]) != (do, ho, wo) or buf.shape[0] != n
+                    or y_off + c > buf.shape[1] or buf.dtype != x.dtype):
                 raise RuntimeError("upsample3d(out=): buffer %s cannot hold a %s slice at channel %d"
                                    % (tuple(buf.shape), (n, c, do, ho, wo), y_off))
             y = _slice_view(buf, y_off, c)
         g = UpGeom(n, d, h, w, do, ho, wo, c, x_ld, y_ld, mode, 1 if align_corners else 0, ratios[0], ratios[1], ratios[2],
-                   F32)
-        with _timed("upsample_fwd c%d" % c, {"flops": 0.0, "bytes": 4.0 * (x.numel() + y.numel())}):
+                   _dt(x))
+        with _timed("upsample_fwd c%d" % c, {"flops": 0.0, "bytes": _esz(x) * (x.numel() + y.numel())}):
             check(L.mri3d_upsample3d_fwd(ctypes.byref(g), _ptr(x), _ptr(y), _stream()), "upsample3d_fwd")
         ctx.geom = g
         ctx.xshape = tuple(x.shape)
@@ -549,9 +640,9 @@ class _Upsample3dFn(torch.autograd.Function):
         dy, dy_ld = _nd(dy)
         dx = _new(ctx.xshape, dy)
         g = UpGeom(g0.n, g0.di, g0.hi, g0.wi, g0.dout, g0.ho, g0.wo, g0.c, g0.c, dy_ld, g0.mode, g0.align_corners, g0.rd,
-                   g0.rh, g0.rw, F32)
+                   g0.rh, g0.rw, _dt(dy))
         ws = _workspace(L.mri3d_upsample3d_workspace_bytes(ctypes.byref(g)), dy.device)
-        with _timed("upsample_bwd c%d" % g.c, {"flops": 0.0, "bytes": 4.0 * (dx.numel() + dy.numel())}):
+        with _timed("upsample_bwd c%d" % g.c, {"flops": 0.0, "bytes": _esz(dy) * (dx.numel() + dy.numel())}):
             check(L.mri3d_upsample3d_bwd(ctypes.byref(g), _ptr(dy), _ptr(dx), _ptr(ws), ws.numel(), _stream()),
                   "upsample3d_bwd")
         return dx, None, None, None, None, None
@@ -595,7 +686,8 @@ def upsample3d(x, size=None, scale_factor=None, mode="nearest", align_corners=No
 class _SoftmaxDiceFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, logits, target, eps):
-        _require_device(logits, target)
+        _require_device(logits)
+        _require_param(target)
         L = _lib.lib()
         logits = _cl(logits)
         target = _cl(target)
@@ -604,7 +696,7 @@ class _SoftmaxDiceFn(torch.autograd.Function):
         if tuple(target.shape) != (n, ct, d, h, w) or ct not in (1, c):
             raise RuntimeError("softmax_dice_loss: target shape %s incompatible with logits %s"
                                % (tuple(target.shape), tuple(logits.shape)))
-        g = DiceGeom(n, d * h * w, c, ct, c, ct, float(eps), F32)
+        g = DiceGeom(n, d * h * w, c, ct, c, ct, float(eps), _dt(logits))
         loss = torch.empty((), dtype=torch.float32, device=logits.device)
         stats = torch.empty(n * c * 3, dtype=torch.float32, device=logits.device)
         ws = _workspace(L.mri3d_softmax_dice_workspace_bytes(ctypes.byref(g)), logits.device)
@@ -637,7 +729,7 @@ def argmax_mask(logits):
     logits = _cl(logits.detach())
     n, c, d, h, w = logits.shape
     out = torch.empty((n, d, h, w), dtype=torch.uint8, device=logits.device)
-    check(L.mri3d_argmax_u8(_ptr(logits), _ptr(out), n * d * h * w, c, c, F32, _stream()), "argmax_u8")
+    check(L.mri3d_argmax_u8(_ptr(logits), _ptr(out), n * d * h * w, c, c, _dt(logits), _stream()), "argmax_u8")
     return out
 
 
@@ -651,7 +743,10 @@ class _CatFn(torch.autograd.Function):
         L = _lib.lib()
         xs = [_cl(x) for x in xs]
         n, _, d, h, w = xs[0].shape
+        es = xs[0].element_size()
         for x in xs:
+            if x.dtype != xs[0].dtype:
+                raise RuntimeError("cat_channels: dtypes differ: %s" % [t.dtype for t in xs])
             if (x.shape[0], x.shape[2], x.shape[3], x.shape[4]) != (n, d, h, w):
                 raise RuntimeError("cat_channels: spatial/batch sizes differ: %s" % [tuple(t.shape) for t in xs])
         ctot = sum(x.shape[1] for x in xs)
@@ -659,7 +754,7 @@ class _CatFn(torch.autograd.Function):
         off = 0
         for x in xs:
             c = x.shape[1]
-            check(L.mri3d_copy_channels(_ptr(x), _ptr(y, off * 4), n * d * h * w, c, c, ctot, F32, _stream()),
+            check(L.mri3d_copy_channels(_ptr(x), _ptr(y, off * es), n * d * h * w, c, c, ctot, _dt(x), _stream()),
                   "copy_channels")
             off += c
         ctx.chans = [x.shape[1] for x in xs]
@@ -675,8 +770,8 @@ class _CatFn(torch.autograd.Function):
         for i, c in enumerate(ctx.chans):
             if ctx.needs_input_grad[i]:
                 dx = _new((n, c, d, h, w), dy)
-                check(L.mri3d_copy_channels(_ptr(dy, off * 4), _ptr(dx), n * d * h * w, c, ctot, c, F32, _stream()),
-                      "copy_channels")
+                check(L.mri3d_copy_channels(_ptr(dy, off * dy.element_size()), _ptr(dx), n * d * h * w, c, ctot, c, _dt(dy),
+                                            _stream()), "copy_channels")
                 outs.append(dx)
             else:
                 outs.append(None)
@@ -733,11 +828,11 @@ class _AddFn(torch.autograd.Function):
         L = _lib.lib()
         a = _cl(a)
         b = _cl(b)
-        if a.shape != b.shape:
-            raise RuntimeError("add: shapes differ %s vs %s" % (tuple(a.shape), tuple(b.shape)))
+        if a.shape != b.shape or a.dtype != b.dtype:
+            raise RuntimeError("add: shapes/dtypes differ %s %s vs %s %s" % (tuple(a.shape), a.dtype, tuple(b.shape), b.dtype))
         n, c, d, h, w = a.shape
         y = _new(a.shape, a)
-        check(L.mri3d_add_channels(_ptr(a), _ptr(b), _ptr(y), n * d * h * w, c, c, c, c, F32, _stream()), "add_channels")
+        check(L.mri3d_add_channels(_ptr(a), _ptr(b), _ptr(y), n * d * h * w, c, c, c, c, _dt(a), _stream()), "add_channels")
         return y
 
     @staticmethod
