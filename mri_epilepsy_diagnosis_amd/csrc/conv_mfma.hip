@@ -73,7 +73,31 @@ __global__ void pack_w_mfma_kernel(const float* __restrict__ w, float* __restric
     }
 }
 
-// ------------------------------------------------------------------ forward / dgrad kernel
+// bf16 image for the 16x16x32 MFMA (conv_mfma_fwd2_kernel<bf16_t>): a 32-byte voxel slice holds 16 channels, so a
+// chunk is 16 channels and a lane's 16-byte fragment is 8 consecutive channels of one tap:
+//   Wp[chunk][tg][nt][lane][s], s = 0..7:  tap = 2*tg + (lane>>5), kc = chunk*16 + 8*((lane>>4)&1) + s  (tap 27 -> 0)
+__global__ void pack_w_mfma_bf16_kernel(const float* __restrict__ w, bf16_t* __restrict__ wp, int Co, int Ci, int dgrad,
+                                        int NTT, int nchunks) {
+    constexpr int TG = 14;
+    const int total = nchunks * TG * NTT * 512;
+    const int Kc = dgrad ? Co : Ci, Nc = dgrad ? Ci : Co;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        const int s = i & 7, lane = (i >> 3) & 63;
+        int t = i >> 9;
+        const int nt = t % NTT;
+        t /= NTT;
+        const int tg = t % TG, chunk = t / TG;
+        const int nc = nt * 16 + (lane & 15);
+        const int tap = 2 * tg + (lane >> 5);
+        const int kc = chunk * 16 + 8 * ((lane >> 4) & 1) + s;
+        float v = 0.f;
+        if (tap < 27 && nc < Nc && kc < Kc)
+            v = dgrad ? w[((size_t)kc * Ci + nc) * 27 + (26 - tap)] : w[((size_t)nc * Ci + kc) * 27 + tap];
+        wp[i] = (bf16_t)v;
+    }
+}
+
+// ------------------------------------------------------------------ forward / dgrad kernel, version 1
 template <int NT, int CK>
 __global__ void __launch_bounds__(256, 2)
 conv_mfma_fwd_kernel(const float* __restrict__ x, const float* __restrict__ wp, const float* __restrict__ bias,
@@ -212,18 +236,25 @@ conv_mfma_fwd_kernel(const float* __restrict__ x, const float* __restrict__ wp, 
 //       of one voxel per lane and the epilogue is a fully coalesced 16-byte store per lane (1 KiB per wave).
 constexpr int kStg = (HVOX * 2 + 255) / 256;  // 16-byte staging pieces per lane per 8-channel chunk (9)
 
-template <int NT>
+// T = float: 8-channel chunks, four 16x16x4 fp32 MFMAs per tap group.  T = bf16_t: the SAME byte geometry (a 32-byte voxel
+// slice = 16 channels, 16-byte pieces, identical staging and LDS addressing) with one v_mfma_f32_16x16x32_bf16 per tap
+// group; the kernel is then bound by the LDS operand reads (the bf16 3x3x3 layers are memory-bound).
+// `wp` is the packed weight image (fp32 or bf16), addressed in 16-byte fragments.
+template <typename T, int NT>
 __global__ void __launch_bounds__(256, 2)
-conv_mfma_fwd2_kernel(const float* __restrict__ x, const float* __restrict__ wp, const float* __restrict__ bias,
-                      float* __restrict__ y, int N, int D, int H, int W, int Kc, int x_ld, int Nc, int y_ld, int NTT,
+conv_mfma_fwd2_kernel(const T* __restrict__ x, const float* __restrict__ wp, const float* __restrict__ bias,
+                      T* __restrict__ y, int N, int D, int H, int W, int Kc, int x_ld, int Nc, int y_ld, int NTT,
                       int gy, int tilesD, int tilesH, int tilesW, int ntiles) {
-    constexpr int CK = 8, CP = 8, TG = 14;
+    constexpr bool kBf16 = sizeof(T) == 2;
+    constexpr int CK = 32 / sizeof(T);   // channels per 32-byte chunk (8 fp32 / 16 bf16)
+    constexpr int PE = 16 / sizeof(T);   // channels per 16-byte piece
+    constexpr int CP = 8, TG = 14;       // CP: LDS voxel pitch in floats (32 bytes)
     constexpr int BUF = kStg * 256 * 4;  // floats per LDS buffer: the halo tile rounded up to kStg 16-byte pieces per lane
     extern __shared__ __attribute__((aligned(16))) float lds[];
 
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int li = lane & 15, kq = lane >> 4;
-    const int nchunks = Kc / CK;
+    const int nchunks = (Kc + CK - 1) / CK;   // bf16 with Kc % 16 == 8: the last chunk's upper piece is zero-filled
     // Tile -> workgroup map (speed only): blocks b and b+8 share an XCD (round-robin dispatch), so XCD k = b & 7 owns the
     // contiguous tile range [ntiles*k/8, ntiles*(k+1)/8) and its workgroups take those tiles round-robin: at any moment
     // the ~64 workgroups of an XCD work on ~64 CONSECUTIVE tiles, whose shared halo voxels then hit that XCD's L2
@@ -269,11 +300,12 @@ conv_mfma_fwd2_kernel(const float* __restrict__ x, const float* __restrict__ wp,
     auto stage_load = [&](const Item& it, int j) -> float4 {
         const int r = srel[j];
         const int gd = it.d0 - 1 + (r >> 16), gh = it.h0 - 1 + ((r >> 8) & 0xff), gw = it.w0 - 1 + (r & 0xff);
-        const bool ok = (unsigned)gd < (unsigned)D && (unsigned)gh < (unsigned)H && (unsigned)gw < (unsigned)W;
+        const int c0 = it.ch * CK + PE * (tid & 1);
+        const bool ok = (unsigned)gd < (unsigned)D && (unsigned)gh < (unsigned)H && (unsigned)gw < (unsigned)W && c0 < Kc;
         okmask = ok ? (okmask | (1u << j)) : (okmask & ~(1u << j));
         const int cd = min(max(gd, 0), D - 1), chh = min(max(gh, 0), H - 1), cw = min(max(gw, 0), W - 1);
-        return *reinterpret_cast<const float4*>(x + ((((int64_t)it.n * D + cd) * H + chh) * W + cw) * x_ld + it.ch * CK +
-                                                4 * (tid & 1));
+        return *reinterpret_cast<const float4*>(x + ((((int64_t)it.n * D + cd) * H + chh) * W + cw) * x_ld +
+                                                (c0 < Kc ? c0 : 0));
     };
     auto stage_store = [&](float* buf, int j, const float4& val) {
         const bool ok = (okmask >> j) & 1u;
@@ -348,13 +380,23 @@ conv_mfma_fwd2_kernel(const float* __restrict__ x, const float* __restrict__ wp,
                 for (int m = 0; m < TH; ++m) aq[an][m] = *reinterpret_cast<const f32x4*>(bufc + o1 + m * HW * CP);
             }
             __builtin_amdgcn_sched_barrier(0);  // keep the prefetches above this tap group's MFMAs
-#pragma unroll
-            for (int s = 0; s < 4; ++s)
+            if constexpr (kBf16) {
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
                     for (int m = 0; m < TH; ++m)
-                        acc[m][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(bq[cb][nt][s], aq[ac][m][s], acc[m][nt], 0, 0, 0);
+                        acc[m][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, bq[cb][nt]),
+                                                                             __builtin_bit_cast(bf16x8_t, aq[ac][m]),
+                                                                             acc[m][nt], 0, 0, 0);
+            } else {
+#pragma unroll
+                for (int s = 0; s < 4; ++s)
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                        for (int m = 0; m < TH; ++m)
+                            acc[m][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(bq[cb][nt][s], aq[ac][m][s], acc[m][nt], 0, 0, 0);
+            }
         }
 
         if (cur.ch == nchunks - 1) {
@@ -378,15 +420,15 @@ conv_mfma_fwd2_kernel(const float* __restrict__ x, const float* __restrict__ wp,
                         for (int m = 0; m < TH; ++m) {
                             const int oh = cur.h0 + m;
                             if (oh < H && ow < W) {
-                                float* yp = y + ((((int64_t)cur.n * D + od) * H + oh) * W + ow) * y_ld + co;
+                                T* yp = y + ((((int64_t)cur.n * D + od) * H + oh) * W + ow) * y_ld + co;
                                 const f32x4 a = acc[m][nt];
                                 if (vec) {
-                                    *reinterpret_cast<float4*>(yp) = make_float4(a[0] + bv.x, a[1] + bv.y, a[2] + bv.z, a[3] + bv.w);
+                                    stf4(yp, make_float4(a[0] + bv.x, a[1] + bv.y, a[2] + bv.z, a[3] + bv.w));
                                 } else {
-                                    yp[0] = a[0] + bv.x;
-                                    if (co + 1 < Nc) yp[1] = a[1] + bv.y;
-                                    if (co + 2 < Nc) yp[2] = a[2] + bv.z;
-                                    if (co + 3 < Nc) yp[3] = a[3] + bv.w;
+                                    stf(yp, a[0] + bv.x);
+                                    if (co + 1 < Nc) stf(yp + 1, a[1] + bv.y);
+                                    if (co + 2 < Nc) stf(yp + 2, a[2] + bv.z);
+                                    if (co + 3 < Nc) stf(yp + 3, a[3] + bv.w);
                                 }
                             }
                         }
@@ -413,13 +455,14 @@ static bool mfma_fwd_plan(const Mri3dConvGeom& g, bool dgrad, MfmaFwdPlan& p) {
     if (!(g.kd == 3 && g.kh == 3 && g.kw == 3 && g.sd == 1 && g.sh == 1 && g.sw == 1 && g.pd == 1 && g.ph == 1 &&
           g.pw == 1 && g.dd == 1 && g.dh == 1 && g.dw == 1))
         return false;
+    const bool bf = g.dtype == MRI3D_BF16;
     const int Kc = dgrad ? g.co : g.ci, Nc = dgrad ? g.ci : g.co;
     const int in_ld = dgrad ? g.y_ld : g.x_ld;
-    if (Kc % 8 != 0 || in_ld % 4 != 0) return false;
+    if (Kc % 8 != 0 || in_ld % (bf ? 8 : 4) != 0) return false;   // 16-byte staging pieces
     if (Nc < 8) return false;  // tiny outputs (e.g. 16->2) stay on the direct kernel
     static const int use_v1 = getenv("MRI3D_FWD_V1") ? atoi(getenv("MRI3D_FWD_V1")) : 0;  // tuning aid (A/B)
-    p.v2 = use_v1 ? 0 : 1;
-    p.CK = (Kc % 16 == 0 && !p.v2) ? 16 : 8;
+    p.v2 = (use_v1 && !bf) ? 0 : 1;
+    p.CK = bf ? 16 : ((Kc % 16 == 0 && !p.v2) ? 16 : 8);
     p.NTT = cdiv(Nc, 16);
     // NT (16-channel N-tiles per wave) is capped by registers: v1 holds 8*NT accumulators + 2-deep A / 3-deep B rings
     // (NT <= 3); v2 adds the staging ring (NT <= 2).  Wider outputs are split over gy passes of the same tile.
@@ -427,14 +470,14 @@ static bool mfma_fwd_plan(const Mri3dConvGeom& g, bool dgrad, MfmaFwdPlan& p) {
     else if (p.NTT % 2 == 0) p.NT = 2;
     else p.NT = 1;
     p.gy = p.NTT / p.NT;
-    p.nchunks = Kc / p.CK;
+    p.nchunks = cdiv(Kc, p.CK);
     p.tilesD = cdiv(g.di, TD);
     p.tilesH = cdiv(g.hi, TH);
     p.tilesW = cdiv(g.wi, TW);
     int64_t nt = (int64_t)g.n * p.tilesD * p.tilesH * p.tilesW;
     if (nt > 0x7fffffff) return false;
     p.ntiles = (int)nt;
-    p.wp_floats = (size_t)p.nchunks * tap_groups(p.CK) * p.NTT * 256;
+    p.wp_floats = (size_t)p.nchunks * (bf ? 14 : tap_groups(p.CK)) * p.NTT * 256;   // 1 KiB per (chunk, tap group, N-tile)
     p.smem = p.v2 ? (size_t)2 * kStg * 256 * 16 : (size_t)HVOX * p.CK * sizeof(float);
     if (p.v2) {
         int64_t st = (int64_t)p.ntiles * p.gy;  // (spatial tile, n-tile block) work units
@@ -456,8 +499,10 @@ static void launch_mfma_fwd(const MfmaFwdPlan& p, const float* in, const float* 
                        out_ld, p.NTT, p.tilesD, p.tilesH, p.tilesW, p.ntiles, ablate);
 }
 
-static int run_mfma_fwd(const Mri3dConvGeom& g, bool dgrad, const float* in, const float* w, const float* bias,
-                        float* out, void* ws, size_t ws_bytes, hipStream_t s) {
+static int run_mfma_fwd(const Mri3dConvGeom& g, bool dgrad, const void* in_v, const float* w, const float* bias,
+                        void* out_v, void* ws, size_t ws_bytes, hipStream_t s) {
+    const float* in = static_cast<const float*>(in_v);   // fp32 views for the fp32-only v1 kernel below
+    float* out = static_cast<float*>(out_v);
     MfmaFwdPlan p;
     MRI3D_REQUIRE(mfma_fwd_plan(g, dgrad, p), MRI3D_ENOTSUP, "conv3d(mfma): unsupported geometry");
     MRI3D_REQUIRE(ws && ws_bytes >= p.wp_floats * sizeof(float), MRI3D_EWORKSPACE, "conv3d(mfma): workspace %zu < %zu",
@@ -468,21 +513,27 @@ static int run_mfma_fwd(const Mri3dConvGeom& g, bool dgrad, const float* in, con
     const int Kc = dgrad ? g.co : g.ci, Nc = dgrad ? g.ci : g.co;
     const int in_ld = dgrad ? g.y_ld : g.x_ld, out_ld = dgrad ? g.x_ld : g.y_ld;
     int total = (int)p.wp_floats;
-    hipLaunchKernelGGL(pack_w_mfma_kernel, dim3(std::min(cdiv(total, 256), 2048)), dim3(256), 0, s, w, wp, g.co, g.ci,
-                       dgrad ? 1 : 0, p.CK, p.NTT, p.nchunks);
+    if (g.dtype == MRI3D_BF16)   // same image size in bytes: 256 floats == 512 bf16 per (chunk, tg, nt)
+        hipLaunchKernelGGL(pack_w_mfma_bf16_kernel, dim3(std::min(cdiv(2 * total, 256), 2048)), dim3(256), 0, s, w,
+                           reinterpret_cast<bf16_t*>(wp), g.co, g.ci, dgrad ? 1 : 0, p.NTT, p.nchunks);
+    else
+        hipLaunchKernelGGL(pack_w_mfma_kernel, dim3(std::min(cdiv(total, 256), 2048)), dim3(256), 0, s, w, wp, g.co, g.ci,
+                           dgrad ? 1 : 0, p.CK, p.NTT, p.nchunks);
     if (p.v2) {
         const int st = p.ntiles * p.gy;
         const size_t smem = p.smem;
 #define MRI3D_FWD2_CASE(NTv)                                                                                          \
     if (p.NT == NTv) {                                                                                                \
-        auto kern = conv_mfma_fwd2_kernel<NTv>;                                                                       \
+        auto kern = conv_mfma_fwd2_kernel<T, NTv>;                                                                    \
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,   \
                                   (int)smem);                                                                         \
-        hipLaunchKernelGGL(kern, dim3(p.grid), dim3(256), smem, s, in, wp, bias, out, g.n, g.di, g.hi, g.wi, Kc,      \
-                           in_ld, Nc, out_ld, p.NTT, p.gy, p.tilesD, p.tilesH, p.tilesW, st);                                \
+        hipLaunchKernelGGL(kern, dim3(p.grid), dim3(256), smem, s, (const T*)in_v, wp, bias, (T*)out_v, g.n, g.di,    \
+                           g.hi, g.wi, Kc, in_ld, Nc, out_ld, p.NTT, p.gy, p.tilesD, p.tilesH, p.tilesW, st);        \
     }
-        MRI3D_FWD2_CASE(1)
-        MRI3D_FWD2_CASE(2)
+        MRI3D_DISPATCH_DTYPE(g.dtype, T, {
+            MRI3D_FWD2_CASE(1)
+            MRI3D_FWD2_CASE(2)
+        });
 #undef MRI3D_FWD2_CASE
         return check_launch(dgrad ? "conv3d_dgrad(mfma2)" : "conv3d_fwd(mfma2)");
     }
@@ -501,12 +552,12 @@ static int run_mfma_fwd(const Mri3dConvGeom& g, bool dgrad, const float* in, con
 
 int conv_mfma_fwd(const Mri3dConvGeom& g, const void* x, const float* w, const float* bias, void* y, void* ws,
                   size_t ws_bytes, hipStream_t s) {
-    return run_mfma_fwd(g, false, static_cast<const float*>(x), w, bias, static_cast<float*>(y), ws, ws_bytes, s);
+    return run_mfma_fwd(g, false, x, w, bias, y, ws, ws_bytes, s);
 }
 
 int conv_mfma_dgrad(const Mri3dConvGeom& g, const void* dy, const float* w, const float* bias, void* dx, void* ws,
                     size_t ws_bytes, hipStream_t s) {
-    return run_mfma_fwd(g, true, static_cast<const float*>(dy), w, bias, static_cast<float*>(dx), ws, ws_bytes, s);
+    return run_mfma_fwd(g, true, dy, w, bias, dx, ws, ws_bytes, s);
 }
 
 // ================================================================== weight gradient
@@ -534,9 +585,11 @@ __device__ __forceinline__ int wg_tap_offset(int tap) {  // halo-voxel offset of
     return ((t / 9) * WHH + (t / 3) % 3) * WHW + t % 3;
 }
 
-template <int CK, bool BIAS>
+// T = storage type of x / dy (bf16 tensors are widened to fp32 when they are staged: the MFMA arithmetic is fp32 in
+// every wgrad kernel below)
+template <typename T, int CK, bool BIAS>
 __global__ void __launch_bounds__(256, 2)
-conv_mfma_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ part, int N, int D,
+conv_mfma_wgrad_kernel(const T* __restrict__ x, const T* __restrict__ dy, float* __restrict__ part, int N, int D,
                        int H, int W, int Ci, int x_ld, int Co, int y_ld, int tilesD, int tilesH, int tilesW, int ntiles,
                        int ablate) {
     constexpr int TG = wg_tap_groups(CK);
@@ -577,8 +630,8 @@ conv_mfma_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ dy
         const int td = tt % tilesD;
         const int n = tt / tilesD;
         const int w0 = tw * WTW, h0 = th * WTH, d0 = td * WTD;
-        const float* xn = x + (int64_t)n * D * H * W * x_ld + cit * CK;
-        const float* dn = dy + (int64_t)n * D * H * W * y_ld + cob * 16;
+        const T* xn = x + (int64_t)n * D * H * W * x_ld + cit * CK;
+        const T* dn = dy + (int64_t)n * D * H * W * y_ld + cob * 16;
 
         __syncthreads();
         if (!(ablate & 1))
@@ -589,12 +642,12 @@ conv_mfma_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ dy
             const int hy = t2 % WHH, dz = t2 / WHH;
             const int gd = d0 - 1 + dz, gh = h0 - 1 + hy, gw = w0 - 1 + wx;
             const bool ok = (unsigned)gd < (unsigned)D && (unsigned)gh < (unsigned)H && (unsigned)gw < (unsigned)W;
-            const float* src = xn + (((int64_t)gd * H + gh) * W + gw) * x_ld + XV * q;
+            const T* src = xn + (((int64_t)gd * H + gh) * W + gw) * x_ld + XV * q;
             if (XV == 4) {
-                float4 val = ok ? *reinterpret_cast<const float4*>(src) : make_float4(0.f, 0.f, 0.f, 0.f);
+                float4 val = ok ? ldf4(src) : make_float4(0.f, 0.f, 0.f, 0.f);
                 *reinterpret_cast<float4*>(xs + v * CP + 4 * q) = val;
             } else {
-                xs[v * CP + q] = ok ? *src : 0.f;
+                xs[v * CP + q] = ok ? ldf(src) : 0.f;
             }
         }
         if (!(ablate & 1))
@@ -605,17 +658,17 @@ conv_mfma_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ dy
             const int hy = t2 % WTH, dz = t2 / WTH;
             const int gd = d0 + dz, gh = h0 + hy, gw = w0 + wx;
             const bool ok = gd < D && gh < H && gw < W;
-            const float* src = dn + (((int64_t)gd * H + gh) * W + gw) * y_ld + 4 * q;
+            const T* src = dn + (((int64_t)gd * H + gh) * W + gw) * y_ld + 4 * q;
             float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
             const int cbase = cob * 16 + 4 * q;
             if (ok) {
                 if (cbase + 3 < Co && (y_ld & 3) == 0) {
-                    val = *reinterpret_cast<const float4*>(src);
+                    val = ldf4(src);
                 } else {
-                    if (cbase + 0 < Co) val.x = src[0];
-                    if (cbase + 1 < Co) val.y = src[1];
-                    if (cbase + 2 < Co) val.z = src[2];
-                    if (cbase + 3 < Co) val.w = src[3];
+                    if (cbase + 0 < Co) val.x = ldf(src);
+                    if (cbase + 1 < Co) val.y = ldf(src + 1);
+                    if (cbase + 2 < Co) val.z = ldf(src + 2);
+                    if (cbase + 3 < Co) val.w = ldf(src + 3);
                 }
             }
             *reinterpret_cast<float4*>(dys + v * 16 + 4 * q) = val;
@@ -684,9 +737,9 @@ __device__ __forceinline__ TileWalk tile_walk(int ntiles) {
 // accumulators in registers, conflict-free 16-row M-tiles) and splits the staging T14-style: the NEXT tile's 16-byte
 // pieces (12 of X + 4 of dY per lane) are fetched into registers before the current tile's 432 MFMAs per wave and
 // written to LDS after them, so HBM/L2 latency is covered by MFMA work and only the LDS write pass stays exposed.
-template <int CK, bool BIAS>
+template <typename T, int CK, bool BIAS>
 __global__ void __launch_bounds__(256, 2)
-conv_mfma_wgrad3_kernel(const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ part, int N, int D,
+conv_mfma_wgrad3_kernel(const T* __restrict__ x, const T* __restrict__ dy, float* __restrict__ part, int N, int D,
                         int H, int W, int Ci, int x_ld, int Co, int y_ld, int tilesD, int tilesH, int tilesW, int ntiles) {
     constexpr int TG = wg_tap_groups(CK);
     constexpr int TGA = TG + (BIAS ? 1 : 0);
@@ -740,7 +793,7 @@ conv_mfma_wgrad3_kernel(const float* __restrict__ x, const float* __restrict__ d
             const bool ok = (unsigned)gd < (unsigned)D && (unsigned)gh < (unsigned)H && (unsigned)gw < (unsigned)W;
             xok = ok ? (xok | (1u << j)) : (xok & ~(1u << j));
             const int cd = min(max(gd, 0), D - 1), chh = min(max(gh, 0), H - 1), cw = min(max(gw, 0), W - 1);
-            px[j] = *reinterpret_cast<const float4*>(x + ((((int64_t)t.n * D + cd) * H + chh) * W + cw) * x_ld + cit * CK +
+            px[j] = ldf4(x + ((((int64_t)t.n * D + cd) * H + chh) * W + cw) * x_ld + cit * CK +
                                                      4 * q);
         }
 #pragma unroll
@@ -753,7 +806,7 @@ conv_mfma_wgrad3_kernel(const float* __restrict__ x, const float* __restrict__ d
             const bool ok = gd < D && gh < H && gw < W && cb < Co;   // host guarantees Co % 4 == 0
             yok = ok ? (yok | (1u << j)) : (yok & ~(1u << j));
             const int cd = min(gd, D - 1), chh = min(gh, H - 1), cw = min(gw, W - 1), cc = min(cb, Co - 4);
-            py[j] = *reinterpret_cast<const float4*>(dy + ((((int64_t)t.n * D + cd) * H + chh) * W + cw) * y_ld + cc);
+            py[j] = ldf4(dy + ((((int64_t)t.n * D + cd) * H + chh) * W + cw) * y_ld + cc);
         }
     };
     auto store_tile = [&]() {
@@ -839,9 +892,9 @@ constexpr int V4YBUF = V4VOX * 16;                 // floats
 
 __device__ __forceinline__ int v4_tap_offset(int tap) { return ((tap / 9) * V4HH + (tap / 3) % 3) * WHW + tap % 3; }
 
-template <bool BIAS>
+template <typename T, bool BIAS>
 __global__ void __launch_bounds__(256, 2)
-conv_mfma_wgrad4_kernel(const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ part, int N, int D,
+conv_mfma_wgrad4_kernel(const T* __restrict__ x, const T* __restrict__ dy, float* __restrict__ part, int N, int D,
                         int H, int W, int Ci, int x_ld, int Co, int y_ld, int tilesD, int tilesH, int tilesW, int ntiles) {
     constexpr int TG = 27, TGA = TG + (BIAS ? 1 : 0), CP = 16;
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -881,7 +934,7 @@ conv_mfma_wgrad4_kernel(const float* __restrict__ x, const float* __restrict__ d
             const bool ok = (unsigned)gd < (unsigned)D && (unsigned)gh < (unsigned)H && (unsigned)gw < (unsigned)W;
             xok = ok ? (xok | (1u << j)) : (xok & ~(1u << j));
             const int cd = min(max(gd, 0), D - 1), chh = min(max(gh, 0), H - 1), cw = min(max(gw, 0), W - 1);
-            px[j] = *reinterpret_cast<const float4*>(x + ((((int64_t)t.n * D + cd) * H + chh) * W + cw) * x_ld + cit * 16 +
+            px[j] = ldf4(x + ((((int64_t)t.n * D + cd) * H + chh) * W + cw) * x_ld + cit * 16 +
                                                      4 * q);
         }
 #pragma unroll
@@ -894,7 +947,7 @@ conv_mfma_wgrad4_kernel(const float* __restrict__ x, const float* __restrict__ d
             const bool ok = gd < D && gh < H && gw < W && cb < Co;   // host guarantees Co % 4 == 0
             yok = ok ? (yok | (1u << j)) : (yok & ~(1u << j));
             const int cd = min(gd, D - 1), chh = min(gh, H - 1), cw = min(gw, W - 1), cc = min(cb, Co - 4);
-            py[j] = *reinterpret_cast<const float4*>(dy + ((((int64_t)t.n * D + cd) * H + chh) * W + cw) * y_ld + cc);
+            py[j] = ldf4(dy + ((((int64_t)t.n * D + cd) * H + chh) * W + cw) * y_ld + cc);
         }
     };
     auto store_tile = [&](float* xb, float* yb) {
@@ -1053,9 +1106,7 @@ static bool mfma_wgrad_plan(const Mri3dConvGeom& g, MfmaWgradPlan& p) {
     return true;
 }
 
-// fp32 storage only: bf16 tensors take the kernels of conv_mfma_bf16.hip
 bool conv_mfma_supported(const Mri3dConvGeom& g, int pass) {
-    if (g.dtype != MRI3D_F32) return false;
     MfmaFwdPlan p;
     MfmaWgradPlan q;
     if (pass == MRI3D_PASS_FWD) return mfma_fwd_plan(g, false, p);
@@ -1073,19 +1124,19 @@ size_t conv_mfma_workspace_bytes(const Mri3dConvGeom& g, int pass) {
     return 0;
 }
 
-template <int CK>
-static void launch_mfma_wgrad(const MfmaWgradPlan& p, const Mri3dConvGeom& g, const float* x, const float* dy,
+template <typename T, int CK>
+static void launch_mfma_wgrad(const MfmaWgradPlan& p, const Mri3dConvGeom& g, const T* x, const T* dy,
                               float* part, bool bias, hipStream_t s) {
     dim3 grid(p.P, p.CIT, p.COB);
     static const int ablate = getenv("MRI3D_ABLATE_W") ? atoi(getenv("MRI3D_ABLATE_W")) : 0;  // tuning aid
     if (bias) {
-        auto kern = conv_mfma_wgrad_kernel<CK, true>;
+        auto kern = conv_mfma_wgrad_kernel<T, CK, true>;
         if (p.smem > 64 * 1024)
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.smem);
         hipLaunchKernelGGL(kern, grid, dim3(256), p.smem, s, x, dy, part, g.n, g.di, g.hi, g.wi, g.ci, g.x_ld, g.co,
                            g.y_ld, p.tilesD, p.tilesH, p.tilesW, p.ntiles, ablate);
     } else {
-        auto kern = conv_mfma_wgrad_kernel<CK, false>;
+        auto kern = conv_mfma_wgrad_kernel<T, CK, false>;
         if (p.smem > 64 * 1024)
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.smem);
         hipLaunchKernelGGL(kern, grid, dim3(256), p.smem, s, x, dy, part, g.n, g.di, g.hi, g.wi, g.ci, g.x_ld, g.co,
@@ -1093,25 +1144,15 @@ static void launch_mfma_wgrad(const MfmaWgradPlan& p, const Mri3dConvGeom& g, co
     }
 }
 
-int conv_mfma_wgrad(const Mri3dConvGeom& g, const void* xv, const void* dyv, float* dw, float* dbias, void* ws,
-                    size_t ws_bytes, hipStream_t s) {
-    const float* x = static_cast<const float*>(xv);
-    const float* dy = static_cast<const float*>(dyv);
-    MfmaWgradPlan p;
-    MRI3D_REQUIRE(mfma_wgrad_plan(g, p), MRI3D_ENOTSUP, "conv3d_wgrad(mfma): unsupported geometry");
-    MRI3D_REQUIRE(ws && ws_bytes >= p.part_floats * sizeof(float), MRI3D_EWORKSPACE,
-                  "conv3d_wgrad(mfma): workspace %zu < %zu", ws_bytes, p.part_floats * sizeof(float));
-    MRI3D_REQUIRE(((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(dy)) & 15) == 0, MRI3D_EINVAL,
-                  "conv3d_wgrad(mfma): x/dy must be 16-byte aligned");
-    float* part = static_cast<float*>(ws);
-    const bool bias = dbias != nullptr;
-    // the kernel template always reserves the bias accumulator slot in the partial layout (TGA = TG + 1) only when BIAS;
-    // keep the layout uniform by always running the BIAS variant when dbias is requested.
+template <typename T>
+static void run_mfma_wgrad(const MfmaWgradPlan& p, const Mri3dConvGeom& g, const T* x, const T* dy, float* part, bool bias,
+                           hipStream_t s) {
+    // the kernel template reserves the bias accumulator slot in the partial layout (TGA = TG + 1) only when BIAS
     if (p.v2 == 2) {
         dim3 grid(p.P, p.CIT, p.COB);
 #define MRI3D_WG4(Bv)                                                                                                 \
     {                                                                                                                 \
-        auto kern = conv_mfma_wgrad4_kernel<Bv>;                                                                      \
+        auto kern = conv_mfma_wgrad4_kernel<T, Bv>;                                                                   \
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,   \
                                   (int)p.smem);                                                                       \
         hipLaunchKernelGGL(kern, grid, dim3(256), p.smem, s, x, dy, part, g.n, g.di, g.hi, g.wi, g.ci, g.x_ld, g.co,  \
@@ -1123,7 +1164,7 @@ int conv_mfma_wgrad(const Mri3dConvGeom& g, const void* xv, const void* dyv, flo
         dim3 grid(p.P, p.CIT, p.COB);
 #define MRI3D_WG3(CKv, Bv)                                                                                            \
     {                                                                                                                 \
-        auto kern = conv_mfma_wgrad3_kernel<CKv, Bv>;                                                                 \
+        auto kern = conv_mfma_wgrad3_kernel<T, CKv, Bv>;                                                              \
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,   \
                                   (int)p.smem);                                                                       \
         hipLaunchKernelGGL(kern, grid, dim3(256), p.smem, s, x, dy, part, g.n, g.di, g.hi, g.wi, g.ci, g.x_ld, g.co,  \
@@ -1132,9 +1173,21 @@ int conv_mfma_wgrad(const Mri3dConvGeom& g, const void* xv, const void* dyv, flo
         if (bias) MRI3D_WG3(8, true)
         else MRI3D_WG3(8, false)
 #undef MRI3D_WG3
-    } else if (p.CK == 16) launch_mfma_wgrad<16>(p, g, x, dy, part, bias, s);
-    else if (p.CK == 8) launch_mfma_wgrad<8>(p, g, x, dy, part, bias, s);
-    else launch_mfma_wgrad<1>(p, g, x, dy, part, bias, s);
+    } else if (p.CK == 16) launch_mfma_wgrad<T, 16>(p, g, x, dy, part, bias, s);
+    else if (p.CK == 8) launch_mfma_wgrad<T, 8>(p, g, x, dy, part, bias, s);
+    else launch_mfma_wgrad<T, 1>(p, g, x, dy, part, bias, s);
+}
+
+int conv_mfma_wgrad(const Mri3dConvGeom& g, const void* x, const void* dy, float* dw, float* dbias, void* ws,
+                    size_t ws_bytes, hipStream_t s) {
+    MfmaWgradPlan p;
+    MRI3D_REQUIRE(mfma_wgrad_plan(g, p), MRI3D_ENOTSUP, "conv3d_wgrad(mfma): unsupported geometry");
+    MRI3D_REQUIRE(ws && ws_bytes >= p.part_floats * sizeof(float), MRI3D_EWORKSPACE,
+                  "conv3d_wgrad(mfma): workspace %zu < %zu", ws_bytes, p.part_floats * sizeof(float));
+    MRI3D_REQUIRE(aligned_vec4(g.dtype, x, dy), MRI3D_EINVAL, "conv3d_wgrad(mfma): x/dy must be aligned to 4 elements");
+    float* part = static_cast<float*>(ws);
+    const bool bias = dbias != nullptr;
+    MRI3D_DISPATCH_DTYPE(g.dtype, T, { run_mfma_wgrad<T>(p, g, static_cast<const T*>(x), static_cast<const T*>(dy), part, bias, s); });
     const int TGA = p.TG + (bias ? 1 : 0);
     const int nelem = p.CIT * p.COB * TGA * 256;
     hipLaunchKernelGGL(wgrad_mfma_reduce_kernel, dim3(cdiv(nelem, 64)), dim3(256), 0, s, part, dw, dbias, p.P, p.CIT,

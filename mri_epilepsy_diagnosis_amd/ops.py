@@ -783,9 +783,14 @@ def cat_channels(xs):
     return _CatFn.apply(*xs)
 
 
+def activation_dtype(x):
+    """Storage type conv outputs (and everything downstream) will have for input x: bf16 inside `autocast()`."""
+    return _autocast_dtype if _autocast_dtype is not None else x.dtype
+
+
 def new_cat_buffer(n, channels, spatial, like):
     """Uninitialised NDHWC buffer that producers fill slice by slice (norm_act(out=), upsample3d(out=))."""
-    return torch.empty((n, channels, *spatial), dtype=like.dtype, device=like.device, memory_format=CL3D)
+    return torch.empty((n, channels, *spatial), dtype=activation_dtype(like), device=like.device, memory_format=CL3D)
 
 
 class _JoinFn(torch.autograd.Function):

@@ -2,6 +2,8 @@
   cfg3  classification encoder (93_6_4 kwargs) + head, batch 4 x 160x192x160, CE step; and the full AE, MSE step
   cfg5  CNN(32^3 patches), batch 512 (stand-in for the 2-D detection net)
   m3d   Modified3DUNet(1,2,8), batch 1 x 160x192x160, soft-Dice step
+  cfg4  unet.UNet(c0=8) under the bf16 autocast region, batch 2 x 160x192x160 per GPU (configs[3]'s per-GPU share);
+        cfg2 = the same step in fp32 for the side-by-side
 Prints ms/step, units/s and the per-operator device-time table (top N)."""
 import os
 import sys
@@ -91,3 +93,23 @@ if which in ("all", "m3d"):
         ops.softmax_dice_loss(m(x6), t6).backward()
         opt.step()
     run("Modified3DUNet(1,2,8) dice step, 1 x 160x192x160", 1, step6)
+for tag, use_bf16 in (("cfg2", False), ("cfg4", True)):
+    if which not in ("all", tag):
+        continue
+    from mri_epilepsy_diagnosis_amd import parallel
+    from mri_epilepsy_diagnosis_amd.unet import UNet
+    torch.manual_seed(0)
+    net = UNet(in_channels=1, out_classes=2, dimensions=3, num_encoding_blocks=3, out_channels_first_layer=8,
+               normalization="batch", upsampling_type="linear", padding=True, activation="PReLU").to(dev)
+    flat = parallel.FlatParams(net)
+    fopt = parallel.FlatAdam(flat, lr=1e-3, weight_decay=0.01, decoupled=True)
+    x7 = torch.randn(2, 1, 160, 192, 160, device=dev, generator=g)
+    t7 = (torch.rand(2, 1, 160, 192, 160, device=dev, generator=g) < 0.1).float()
+
+    def step7():
+        flat.zero_grad()
+        with ops.autocast(enabled=use_bf16):
+            loss = ops.softmax_dice_loss(net(x7), t7)
+        loss.backward()
+        fopt.step(flat.all_reduce())
+    run("%s unet.UNet(c0=8) %s dice step, 2 x 160x192x160" % (tag, "bf16 autocast" if use_bf16 else "fp32"), 2, step7)
