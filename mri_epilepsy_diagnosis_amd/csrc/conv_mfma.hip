@@ -1023,6 +1023,174 @@ conv_mfma_wgrad4_kernel(const T* __restrict__ x, const T* __restrict__ dy, float
     for (int i = tid; i < TGA * 256; i += 256) out[i] = red[i];
 }
 
+// ------------------------------------------------------------------ weight gradient on the bf16 MFMA (bf16 tensors)
+// v_mfma_f32_16x16x32_bf16 sums over K = 32 VOXELS, and a lane's operand is 8 CONSECUTIVE k: the NDHWC tile has to be
+// transposed to [channel][voxel] on its way into LDS.  A workgroup stages a 2x6x32-voxel tile:
+//   X halo: 4 x 8 rows of (32 voxels + the two W-halo voxels) for the 16 input channels of its ci-tile,
+//   dY:     2 x 6 rows of 32 voxels for the 16 output channels of its co-tile,
+// each lane loading 8 consecutive voxels x 8 channels (8 x 16 B) and transposing them in registers (v_perm) into eight
+// 16-byte LDS writes.  A (row, channel) line is 64 B of voxels + 16 B of padding whose first dword holds the two halo
+// voxels (lo = voxel 32, hi = voxel -1); the 80-byte pitch makes the 16-lane ds_read_b128 of 16 channels conflict-free.
+// The kw = 0 / 2 taps are the same 32 voxels shifted by one: they are built from the aligned fragment and its two
+// neighbour dwords with v_alignbyte instead of extra LDS traffic (1 b128 + 2 b32 reads feed 3 MFMAs).
+// Accumulators: 27 taps x (16 ci x 16 co) per wave (+1 for dbias, fed with A = 1), same partial layout as v4.
+constexpr int BTD = 2, BTH = 6, BTW = 32;
+constexpr int BHD = BTD + 2, BHH = BTH + 2;
+constexpr int BXR = BHD * BHH;            // 32 X rows
+constexpr int BYR = BTD * BTH;            // 12 dY rows
+constexpr int BRS = 80;                   // bytes per (row, channel) line
+constexpr int BXS = BXR * 16 * BRS;       // 40960 B
+constexpr int BYS = BYR * 16 * BRS;       // 15360 B
+
+// eight voxels x eight channels (v[j] = the 16-byte channel vector of voxel j) -> out[c] = the 8 voxels of channel c
+__device__ __forceinline__ void transpose8x8_bf16(const uint4 (&v)[8], uint4 (&out)[8]) {
+    const unsigned* vw = reinterpret_cast<const unsigned*>(v);
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+        const int cd = c >> 1;
+        const unsigned sel = (c & 1) ? 0x07060302u : 0x05040100u;   // high / low halves of (S1 = even voxel, S0 = odd voxel)
+        out[c].x = __builtin_amdgcn_perm(vw[1 * 4 + cd], vw[0 * 4 + cd], sel);
+        out[c].y = __builtin_amdgcn_perm(vw[3 * 4 + cd], vw[2 * 4 + cd], sel);
+        out[c].z = __builtin_amdgcn_perm(vw[5 * 4 + cd], vw[4 * 4 + cd], sel);
+        out[c].w = __builtin_amdgcn_perm(vw[7 * 4 + cd], vw[6 * 4 + cd], sel);
+    }
+}
+
+template <bool BIAS>
+__global__ void __launch_bounds__(256, 2)
+conv_mfma_wgrad_bf16_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ dy, float* __restrict__ part, int N,
+                            int D, int H, int W, int Ci, int x_ld, int Co, int y_ld, int tilesD, int tilesH, int tilesW,
+                            int ntiles) {
+    constexpr int TG = 27, TGA = TG + (BIAS ? 1 : 0);
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    char* xs = reinterpret_cast<char*>(lds);
+    char* ys = xs + BXS;
+
+    const int cit = blockIdx.y, cob = blockIdx.z;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int li = lane & 15, kq = lane >> 4;
+
+    f32x4 acc[TGA];
+#pragma unroll
+    for (int t = 0; t < TGA; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // staging roles (fixed per lane)
+    const int s_half = tid & 1, s_wg = (tid >> 1) & 3, s_row = tid >> 3;     // X: 32 rows x 4 w-groups x 2 channel halves
+    const int h_half = tid & 1, h_side = (tid >> 1) & 1, h_row = tid >> 2;   // X halo voxels (tid < 128)
+    const uint4 zero4 = make_uint4(0u, 0u, 0u, 0u);
+    // per-lane operand offsets
+    const int p_off = kq == 0 ? 64 : 16 * kq - 4, n_off = kq == 3 ? 64 : 16 * kq + 16;
+    bf16x8_t ones;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) ones[i] = (bf16_t)1.0f;
+
+    const TileWalk tw = tile_walk(ntiles);
+    for (int k = 0; k < tw.count; ++k) {
+        int tile = tw.first + k * tw.stride;
+        const int w0 = (tile % tilesW) * BTW;
+        tile /= tilesW;
+        const int h0 = (tile % tilesH) * BTH;
+        tile /= tilesH;
+        const int d0 = (tile % tilesD) * BTD;
+        const int n = tile / tilesD;
+
+        __syncthreads();   // the previous tile's MFMAs are done with the buffers
+        {   // ---- X: 8 voxels x 8 channels per lane
+            const int gd = d0 - 1 + s_row / BHH, gh = h0 - 1 + s_row % BHH;
+            const int c0 = cit * 16 + 8 * s_half;
+            const bool rok = (unsigned)gd < (unsigned)D && (unsigned)gh < (unsigned)H && c0 < Ci;
+            const bf16_t* src = x + ((((int64_t)n * D + (rok ? gd : 0)) * H + (rok ? gh : 0)) * W) * x_ld + (c0 < Ci ? c0 : 0);
+            uint4 v[8], o[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int gw = w0 + 8 * s_wg + j;
+                v[j] = (rok && gw < W) ? *reinterpret_cast<const uint4*>(src + (int64_t)gw * x_ld) : zero4;
+            }
+            transpose8x8_bf16(v, o);
+#pragma unroll
+            for (int c = 0; c < 8; ++c)
+                *reinterpret_cast<uint4*>(xs + (s_row * 16 + 8 * s_half + c) * BRS + 16 * s_wg) = o[c];
+        }
+        if (tid < 128) {   // ---- X halo voxels w0-1 (hi half) and w0+32 (lo half)
+            const int gd = d0 - 1 + h_row / BHH, gh = h0 - 1 + h_row % BHH, gw = h_side ? w0 + BTW : w0 - 1;
+            const int c0 = cit * 16 + 8 * h_half;
+            const bool ok = (unsigned)gd < (unsigned)D && (unsigned)gh < (unsigned)H && (unsigned)gw < (unsigned)W && c0 < Ci;
+            uint4 hv = zero4;
+            if (ok) hv = *reinterpret_cast<const uint4*>(x + ((((int64_t)n * D + gd) * H + gh) * W + gw) * x_ld + c0);
+            const unsigned* hw = reinterpret_cast<const unsigned*>(&hv);
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                const unsigned short val = (unsigned short)((c & 1) ? (hw[c >> 1] >> 16) : (hw[c >> 1] & 0xffffu));
+                *reinterpret_cast<unsigned short*>(xs + (h_row * 16 + 8 * h_half + c) * BRS + 64 + (h_side ? 0 : 2)) = val;
+            }
+        }
+        if (tid < BYR * 8) {   // ---- dY: 12 rows x 4 w-groups x 2 channel halves
+            const int gd = d0 + s_row / BTH, gh = h0 + s_row % BTH;
+            const int c0 = cob * 16 + 8 * s_half;
+            const bool rok = gd < D && gh < H && c0 < Co;       // host guarantees Co % 8 == 0
+            const bf16_t* src = dy + ((((int64_t)n * D + (rok ? gd : 0)) * H + (rok ? gh : 0)) * W) * y_ld + (c0 < Co ? c0 : 0);
+            uint4 v[8], o[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int gw = w0 + 8 * s_wg + j;
+                v[j] = (rok && gw < W) ? *reinterpret_cast<const uint4*>(src + (int64_t)gw * y_ld) : zero4;
+            }
+            transpose8x8_bf16(v, o);
+#pragma unroll
+            for (int c = 0; c < 8; ++c)
+                *reinterpret_cast<uint4*>(ys + (s_row * 16 + 8 * s_half + c) * BRS + 16 * s_wg) = o[c];
+        }
+        __syncthreads();
+
+        // ---- 3 output rows per wave x 9 (kd, kh) x 3 kw MFMAs
+#pragma unroll 1
+        for (int r = 0; r < BYR / 4; ++r) {
+            const int orow = wv * (BYR / 4) + r;
+            const int dz = orow / BTH, hy = orow % BTH;
+            const bf16x8_t b = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(ys + (orow * 16 + li) * BRS + 16 * kq));
+            if (BIAS) acc[TG] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, b, acc[TG], 0, 0, 0);
+#pragma unroll
+            for (int kdh = 0; kdh < 9; ++kdh) {
+                const int xr = (dz + kdh / 3) * BHH + hy + kdh % 3;
+                const char* base = xs + (xr * 16 + li) * BRS;
+                const uint4 g = *reinterpret_cast<const uint4*>(base + 16 * kq);
+                const unsigned pp = *reinterpret_cast<const unsigned*>(base + p_off);
+                const unsigned nn = *reinterpret_cast<const unsigned*>(base + n_off);
+                uint4 a0, a2;
+                a0.x = __builtin_amdgcn_alignbyte(g.x, pp, 2);
+                a0.y = __builtin_amdgcn_alignbyte(g.y, g.x, 2);
+                a0.z = __builtin_amdgcn_alignbyte(g.z, g.y, 2);
+                a0.w = __builtin_amdgcn_alignbyte(g.w, g.z, 2);
+                a2.x = a0.y;
+                a2.y = a0.z;
+                a2.z = a0.w;
+                a2.w = __builtin_amdgcn_alignbyte(nn, g.w, 2);
+                acc[kdh * 3 + 0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a0), b, acc[kdh * 3 + 0], 0, 0, 0);
+                acc[kdh * 3 + 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, g), b, acc[kdh * 3 + 1], 0, 0, 0);
+                acc[kdh * 3 + 2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a2), b, acc[kdh * 3 + 2], 0, 0, 0);
+            }
+        }
+    }
+
+    // combine the 4 waves in a fixed order through LDS, then one partial per workgroup
+    __syncthreads();
+    float* red = lds;  // [TGA][256]
+    for (int w = 0; w < 4; ++w) {
+        if (wv == w) {
+#pragma unroll
+            for (int t = 0; t < TGA; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int o = t * 256 + (4 * kq + r) * 16 + li;
+                    red[o] = (w == 0) ? acc[t][r] : red[o] + acc[t][r];
+                }
+        }
+        __syncthreads();
+    }
+    float* out = part + (((size_t)blockIdx.x * gridDim.y + cit) * gridDim.z + cob) * (TGA * 256);
+    for (int i = tid; i < TGA * 256; i += 256) out[i] = red[i];
+}
+
 // dw[co][ci][tap] = sum_p part[p][cit][cob][tg][row][col]   (+ dbias[co] from the extra accumulator of cit == 0)
 // Threads walk the partial layout itself (64 consecutive elements per wave => coalesced 256-byte reads of every
 // partial), 4 partial-lanes per element combined through LDS in double; the (tiny) result is scattered into torch's
@@ -1071,18 +1239,22 @@ static bool mfma_wgrad_plan(const Mri3dConvGeom& g, MfmaWgradPlan& p) {
         return false;
     static const int use_v1 = getenv("MRI3D_WGRAD_V1") ? atoi(getenv("MRI3D_WGRAD_V1")) : 0;  // tuning aid (A/B)
     // kernel version: 0 = v1 (any CK), 1 = v3 (CK = 8, register prefetch), 2 = v4 (CK = 16, small double-buffered tile)
+    // 3 = bf16 MFMA (bf16 tensors, Cin % 8 == 0: a 16-channel ci-tile whose upper half may be empty)
     p.v2 = (!use_v1 && g.ci % 8 == 0 && g.co % 4 == 0 && g.y_ld % 4 == 0) ? (g.ci % 16 == 0 ? 2 : 1) : 0;
-    if (g.ci % 16 == 0) p.CK = 16;
+    static const int no_bf = getenv("MRI3D_WGRAD_BF16_OFF") ? atoi(getenv("MRI3D_WGRAD_BF16_OFF")) : 0;   // tuning aid (A/B)
+    if (g.dtype == MRI3D_BF16 && !no_bf && g.ci % 8 == 0 && g.co % 8 == 0 && g.x_ld % 8 == 0 && g.y_ld % 8 == 0) p.v2 = 3;
+    if (p.v2 == 3) p.CK = 16;
+    else if (g.ci % 16 == 0) p.CK = 16;
     else if (g.ci % 8 == 0) p.CK = 8;
     else if (g.ci == 1) p.CK = 1;
     else return false;
     if (p.CK >= 4 && g.x_ld % 4 != 0) return false;
-    p.CIT = g.ci / p.CK;
+    p.CIT = cdiv(g.ci, p.CK);
     p.COB = cdiv(g.co, 16);
     p.TG = wg_tap_groups(p.CK);
-    p.tilesD = cdiv(g.di, WTD);
-    p.tilesH = cdiv(g.hi, p.v2 == 2 ? V4TH : WTH);
-    p.tilesW = cdiv(g.wi, WTW);
+    p.tilesD = cdiv(g.di, p.v2 == 3 ? BTD : WTD);
+    p.tilesH = cdiv(g.hi, p.v2 == 3 ? BTH : (p.v2 == 2 ? V4TH : WTH));
+    p.tilesW = cdiv(g.wi, p.v2 == 3 ? BTW : WTW);
     int64_t nt = (int64_t)g.n * p.tilesD * p.tilesH * p.tilesW;
     if (nt > 0x7fffffff) return false;
     p.ntiles = (int)nt;
@@ -1102,6 +1274,8 @@ static bool mfma_wgrad_plan(const Mri3dConvGeom& g, MfmaWgradPlan& p) {
         p.smem = std::max<size_t>(xbuf + (size_t)WVOX * 16, red) * sizeof(float);
     } else if (p.v2 == 2) {
         p.smem = std::max<size_t>((size_t)2 * V4XBUF + 2 * V4YBUF, red) * sizeof(float);
+    } else if (p.v2 == 3) {
+        p.smem = std::max<size_t>((size_t)BXS + BYS, red * sizeof(float));
     }
     return true;
 }
@@ -1148,7 +1322,21 @@ template <typename T>
 static void run_mfma_wgrad(const MfmaWgradPlan& p, const Mri3dConvGeom& g, const T* x, const T* dy, float* part, bool bias,
                            hipStream_t s) {
     // the kernel template reserves the bias accumulator slot in the partial layout (TGA = TG + 1) only when BIAS
-    if (p.v2 == 2) {
+    if (p.v2 == 3) {
+        if constexpr (sizeof(T) == 2) {
+            dim3 grid(p.P, p.CIT, p.COB);
+#define MRI3D_WGB(Bv)                                                                                                 \
+    {                                                                                                                 \
+        auto kern = conv_mfma_wgrad_bf16_kernel<Bv>;                                                                  \
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,   \
+                                  (int)p.smem);                                                                       \
+        hipLaunchKernelGGL(kern, grid, dim3(256), p.smem, s, x, dy, part, g.n, g.di, g.hi, g.wi, g.ci, g.x_ld, g.co,  \
+                           g.y_ld, p.tilesD, p.tilesH, p.tilesW, p.ntiles);                                           \
+    }
+            if (bias) MRI3D_WGB(true) else MRI3D_WGB(false)
+#undef MRI3D_WGB
+        }
+    } else if (p.v2 == 2) {
         dim3 grid(p.P, p.CIT, p.COB);
 #define MRI3D_WG4(Bv)                                                                                                 \
     {                                                                                                                 \
@@ -1185,6 +1373,8 @@ int conv_mfma_wgrad(const Mri3dConvGeom& g, const void* x, const void* dy, float
     MRI3D_REQUIRE(ws && ws_bytes >= p.part_floats * sizeof(float), MRI3D_EWORKSPACE,
                   "conv3d_wgrad(mfma): workspace %zu < %zu", ws_bytes, p.part_floats * sizeof(float));
     MRI3D_REQUIRE(aligned_vec4(g.dtype, x, dy), MRI3D_EINVAL, "conv3d_wgrad(mfma): x/dy must be aligned to 4 elements");
+    MRI3D_REQUIRE(p.v2 != 3 || ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(dy)) & 15) == 0, MRI3D_EINVAL,
+                  "conv3d_wgrad(bf16 mfma): x/dy must be 16-byte aligned");
     float* part = static_cast<float*>(ws);
     const bool bias = dbias != nullptr;
     MRI3D_DISPATCH_DTYPE(g.dtype, T, { run_mfma_wgrad<T>(p, g, static_cast<const T*>(x), static_cast<const T*>(dy), part, bias, s); });
