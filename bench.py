@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py — MRI volumes/sec (fwd + bwd + optimizer step) of the 3-D U-Net at 160x192x160 on N MI355X GPUs.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--dtype f32|bf16]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
 Workload (BASELINE.json configs[1], the configuration the metric is quoted on): `unet.UNet`(c0=8, 3 encoding blocks,
@@ -9,6 +9,8 @@ BatchNorm + PReLU, trilinear upsampling) on a batch of 2 synthetic z-normalised-
 1x160x192x160 per GPU, soft-Dice loss against a Bernoulli(0.1) mask, AdamW.  One step = forward + softmax-Dice +
 backward + (flat-gradient RCCL all-reduce when N > 1) + fused AdamW on every rank (weak scaling: 2 volumes per GPU).
 Inputs are generated on the device before the timed region.
+`--dtype bf16` (not the default, not the headline) runs the same step inside the bf16 storage region — BASELINE configs[3]'s
+per-GPU share (2 volumes per GPU, batch 16 over 8 GPUs): bf16 activations, fp32 accumulate / parameters / loss.
 
 Prints ONE JSON line on rank 0 (see the driver contract), including
   roofline     — the dominant kernel (largest share of step time) measured live with stream events inside the timed
@@ -29,6 +31,7 @@ if ROOT not in sys.path:
 import torch  # noqa: E402
 
 PEAK_F32_TFLOPS = 157.3  # MI355X dense fp32 (vector == fp32-input MFMA), MI355X_MICROARCH.md
+PEAK_BF16_TFLOPS = 2516.0  # MI355X dense bf16 MFMA
 PEAK_HBM_GBS = 8000.0    # HBM3E spec
 SHAPE = (160, 192, 160)
 PER_GPU_BATCH = 2
@@ -84,6 +87,7 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--dtype", choices=("f32", "bf16"), default="f32")
     args = ap.parse_args()
 
     from mri_epilepsy_diagnosis_amd import _lib, ops, parallel
@@ -106,9 +110,13 @@ def main():
     t = (torch.rand(PER_GPU_BATCH, 1, *SHAPE, device=device, generator=g) < 0.1).float()
     model.train()
 
+    bf16 = args.dtype == "bf16"
+    peak_tflops = PEAK_BF16_TFLOPS if bf16 else PEAK_F32_TFLOPS
+
     def step():
         opt.zero_grad()
-        loss = ops.softmax_dice_loss(model(x), t)
+        with ops.autocast(enabled=bf16):
+            loss = ops.softmax_dice_loss(model(x), t)
         loss.backward()
         opt.step(flat.all_reduce())
         return loss
@@ -142,8 +150,8 @@ def main():
         avg_s = dom["ms"] / dom["calls"] / 1e3
         work = dom["work"] or {"flops": 0.0, "bytes": 0.0}
         ai = work["flops"] / max(work["bytes"], 1.0)
-        if ai > PEAK_F32_TFLOPS * 1e12 / (PEAK_HBM_GBS * 1e9):
-            achieved, peak, unit, bound = work["flops"] / avg_s / 1e12, PEAK_F32_TFLOPS, "TFLOP/s", "mfma"
+        if ai > peak_tflops * 1e12 / (PEAK_HBM_GBS * 1e9):
+            achieved, peak, unit, bound = work["flops"] / avg_s / 1e12, peak_tflops, "TFLOP/s", "mfma"
         else:
             achieved, peak, unit, bound = work["bytes"] / avg_s / 1e9, PEAK_HBM_GBS, "GB/s", "hbm"
         # HBM traffic per launch of the dominant kernel: PMC counters cannot be read from inside this process, so the figure
@@ -180,15 +188,17 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f32",
+            "dtype": args.dtype,
             "data": "synthetic",
             "config": {"workload": "unet.UNet(c0=8, 3 enc blocks, BN+PReLU, trilinear) fwd+softmax-Dice+bwd+AdamW, "
-                                   "batch 2 x 1x160x192x160 fp32 per GPU (BASELINE configs[1])",
+                                   + ("batch 2 x 1x160x192x160 per GPU, bf16 activations / fp32 accumulate+master weights "
+                                      "(BASELINE configs[3] per-GPU share)" if bf16 else
+                                      "batch 2 x 1x160x192x160 fp32 per GPU (BASELINE configs[1])"),
                        "global_batch": world * PER_GPU_BATCH, "volume": list(SHAPE),
                        "parallelism": "dp%d" % world, "final_loss": round(final_loss, 6)},
             "roofline": roofline,
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and not bf16:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)
     if world > 1:
