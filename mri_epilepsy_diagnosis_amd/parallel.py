@@ -110,3 +110,52 @@ def shard_range(n_items, rank, world):
     base, rem = divmod(n_items, world)
     lo = rank * base + min(rank, rem)
     return lo, lo + base + (1 if rank < rem else 0)
+
+
+class CapturedStep:
+    """`zero_grad -> loss = loss_fn() -> loss.backward()` recorded ONCE into a hipGraph and replayed per step.
+
+    A training step of the U-Net is ~300 kernel launches issued from Python autograd; at bf16 speeds the host becomes the
+    bound (20 % of the wall time measured as launch gaps).  All shapes are static, every kernel of this library is
+    enqueued on torch's current stream and all memory comes from torch's caching allocator, so the whole forward +
+    backward can be stream-captured (torch.cuda.graph == hipStreamBeginCapture) and replayed with one launch.  The
+    gradient all-reduce and the optimizer step stay outside the graph (the collective is not captured, and the Adam
+    bias correction takes the host-side step count).
+
+    Usage:   cap = CapturedStep(flat, lambda: ops.softmax_dice_loss(model(x), t));  loss = cap.run()
+    The inputs referenced by `loss_fn` must be static tensors (update them in place between steps).
+    """
+
+    def __init__(self, flat, loss_fn, warmup=3):
+        self.flat = flat
+        self.loss_fn = loss_fn
+        self.graph = None
+        self.loss = None
+        self.warmup = warmup
+
+    def _eager(self):
+        self.flat.zero_grad()
+        loss = self.loss_fn()
+        loss.backward()
+        return loss
+
+    def capture(self):
+        # warm-up on a side stream (allocator pools, lazy workspace growth, hipFuncSetAttribute) as torch recommends
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            for _ in range(self.warmup):
+                self._eager()
+        torch.cuda.current_stream().wait_stream(s)
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            self.loss = self._eager()
+        self.graph = g
+        return self
+
+    def run(self):
+        if self.graph is None:
+            return self._eager()
+        self.graph.replay()
+        return self.loss
