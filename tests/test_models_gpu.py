@@ -340,3 +340,35 @@ def test_full_size_layer_parity_48_16_slab():
     assert_close(to_ncdhw(xd.grad), xr.grad, what="dx")
     assert_close(w.grad.cpu(), conv.weight.grad, what="dw")
     assert_close(b.grad.cpu(), conv.bias.grad, what="db")
+
+
+@pytest.mark.parametrize("bf16", [False, True])
+def test_captured_step_replays_eager_step_bit_exactly(bf16):
+    """parallel.CapturedStep: forward+backward recorded once into a hipGraph must reproduce the eagerly launched step
+    (same kernels, deterministic reductions => identical loss and flat gradient), also after the inputs change in place."""
+    torch.manual_seed(3)
+    net = _unet(8).to(DEV)
+    flat = parallel.FlatParams(net)
+    x = torch.randn(1, 1, 32, 32, 32, device=DEV)
+    t = (torch.rand(1, 1, 32, 32, 32, device=DEV) < 0.2).float()
+
+    def loss_fn():
+        with ops.autocast(enabled=bf16):
+            return ops.softmax_dice_loss(net(x), t)
+
+    cap = parallel.CapturedStep(flat, loss_fn).capture()
+    state = {k: v.clone() for k, v in net.state_dict().items()}   # BN running statistics advance with every step
+    for trial in range(2):
+        if trial == 1:
+            x.copy_(torch.randn_like(x))
+            t.copy_((torch.rand_like(t) < 0.3).float())
+        net.load_state_dict(state)
+        l_g = cap.run().clone()
+        g_g = flat.grad.clone()
+        rm_g = net.encoder.encoding_blocks[0].conv2.norm_layer.running_mean.clone()
+        net.load_state_dict(state)
+        l_e = cap._eager().clone()
+        assert torch.equal(l_g, l_e), (l_g.item(), l_e.item())
+        assert torch.equal(g_g, flat.grad)
+        assert torch.equal(rm_g, net.encoder.encoding_blocks[0].conv2.norm_layer.running_mean)
+    assert g_g.abs().max().item() > 0
