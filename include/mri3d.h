@@ -166,6 +166,14 @@ int mri3d_softmax_dice_bwd(const Mri3dDiceGeom* g, const void* logits, const voi
 int mri3d_argmax_u8(const void* logits, uint8_t* out, int64_t nvox, int32_t c, int32_t ld, int32_t dtype,
                     mri3d_stream_t stream);
 
+/* Overlap counts of two uint8 masks for the validation metrics of validate_dsc_asd (segmentation/routine.py:198-235;
+ * compute_dice_coefficient segmentation/metrics.py:312-329; get_iou_score routine.py:198-203), exact integers:
+ *   counts[0] = sum(gt)  [1] = sum(pred)  [2] = sum(gt & pred)  [3] = #(gt>0 and pred>0)  [4] = #(gt>0 or pred>0)
+ *   Dice = 2*counts[2] / (counts[0] + counts[1])   (NaN when the denominator is 0);   IoU = counts[3] / counts[4]. */
+size_t mri3d_mask_overlap_workspace_bytes(void);
+int mri3d_mask_overlap(const uint8_t* pred, const uint8_t* gt, int64_t nvox, int64_t* counts, void* workspace,
+                       size_t ws_bytes, mri3d_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Channel-slice plumbing: torch.cat along channels (unet.UNet decoder, modified_3dunet.py:158-178) and
  * residual adds (modified_3dunet.py:108, cnn_model.py:34).

@@ -10,6 +10,7 @@
 //
 // HBM-bound: forward = one read of logits+target; backward = one read of both + one write of dlogits.
 #include "common.h"
+#include <algorithm>
 
 namespace mri3d {
 
@@ -160,6 +161,65 @@ argmax_u8_kernel(const T* __restrict__ logits, uint8_t* __restrict__ out, int64_
     }
 }
 
+// ------------------------------------------------------------------ mask overlap counts (validation metrics)
+// validate_dsc_asd scores the arg-max mask against the label map on the host (segmentation/routine.py:198-235,
+// metrics.py:312-329): Dice = 2*sum(gt & pred) / (sum(gt) + sum(pred)), IoU = #(pred>0 and gt>0) / #(pred>0 or gt>0).
+// All five sums are integers, so they are taken on the device in one pass over the two uint8 masks (16 voxels per lane
+// per load) and only 40 bytes leave the GPU instead of two volumes; integer addition is order-independent => exact.
+//   out[0] = sum(gt)  out[1] = sum(pred)  out[2] = sum(gt & pred)  out[3] = #(gt>0 & pred>0)  out[4] = #(gt>0 | pred>0)
+constexpr int kOvlBlocks = 512;
+
+__device__ __forceinline__ void ovl_acc(unsigned g, unsigned p, unsigned long long (&c)[5]) {
+    c[0] += g;
+    c[1] += p;
+    c[2] += g & p;
+    c[3] += (g != 0u && p != 0u) ? 1u : 0u;
+    c[4] += (g != 0u || p != 0u) ? 1u : 0u;
+}
+
+__global__ void __launch_bounds__(256)
+mask_overlap_kernel(const uint8_t* __restrict__ pred, const uint8_t* __restrict__ gt, int64_t n, int vec,
+                    unsigned long long* __restrict__ part) {
+    __shared__ unsigned long long red[4][5];
+    unsigned long long c[5] = {0ull, 0ull, 0ull, 0ull, 0ull};
+    const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x, nth = (int64_t)gridDim.x * blockDim.x;
+    int64_t done = 0;
+    if (vec) {
+        const int64_t n16 = n >> 4;
+        const uint4* p4 = reinterpret_cast<const uint4*>(pred);
+        const uint4* g4 = reinterpret_cast<const uint4*>(gt);
+        for (int64_t i = tid; i < n16; i += nth) {
+            const uint4 pv = p4[i], gv = g4[i];
+            const unsigned pw[4] = {pv.x, pv.y, pv.z, pv.w}, gw[4] = {gv.x, gv.y, gv.z, gv.w};
+#pragma unroll
+            for (int w = 0; w < 4; ++w)
+#pragma unroll
+                for (int b = 0; b < 4; ++b) ovl_acc((gw[w] >> (8 * b)) & 0xffu, (pw[w] >> (8 * b)) & 0xffu, c);
+        }
+        done = n16 << 4;
+    }
+    for (int64_t i = done + tid; i < n; i += nth) ovl_acc(gt[i], pred[i], c);
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+#pragma unroll
+    for (int k = 0; k < 5; ++k) {
+        unsigned long long v = c[k];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+        if (lane == 0) red[wave][k] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < 5)
+        part[(size_t)blockIdx.x * 5 + threadIdx.x] = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+}
+
+__global__ void mask_overlap_finalize_kernel(const unsigned long long* __restrict__ part, int nblk, int64_t* __restrict__ out) {
+    const int k = threadIdx.x;
+    if (k >= 5) return;
+    unsigned long long s = 0ull;
+    for (int b = 0; b < nblk; ++b) s += part[(size_t)b * 5 + k];
+    out[k] = (int64_t)s;
+}
+
 static int dice_blocks(const Mri3dDiceGeom& g) {
     int64_t want = cdiv64(g.vox, 256 * 4);
     int cap = kDiceMaxBlocks / g.n;
@@ -245,4 +305,22 @@ extern "C" int mri3d_argmax_u8(const void* logits, uint8_t* out, int64_t nvox, i
                            ld);
     });
     return check_launch("argmax_u8");
+}
+
+extern "C" size_t mri3d_mask_overlap_workspace_bytes(void) { return (size_t)kOvlBlocks * 5 * sizeof(unsigned long long); }
+
+extern "C" int mri3d_mask_overlap(const uint8_t* pred, const uint8_t* gt, int64_t nvox, int64_t* counts, void* workspace,
+                                  size_t ws_bytes, mri3d_stream_t stream) {
+    MRI3D_REQUIRE(pred && gt && counts && nvox > 0, MRI3D_EINVAL, "mask_overlap: bad arguments");
+    MRI3D_REQUIRE(workspace && ws_bytes >= mri3d_mask_overlap_workspace_bytes() &&
+                      (reinterpret_cast<uintptr_t>(workspace) & 7) == 0,
+                  MRI3D_EWORKSPACE, "mask_overlap: workspace %zu < %zu", ws_bytes, mri3d_mask_overlap_workspace_bytes());
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int vec = ((reinterpret_cast<uintptr_t>(pred) | reinterpret_cast<uintptr_t>(gt)) & 15) == 0 ? 1 : 0;
+    int nblk = (int)std::min<int64_t>(kOvlBlocks, cdiv64(nvox, 256 * 16));
+    if (nblk < 1) nblk = 1;
+    unsigned long long* part = static_cast<unsigned long long*>(workspace);
+    hipLaunchKernelGGL(mask_overlap_kernel, dim3(nblk), dim3(256), 0, s, pred, gt, nvox, vec, part);
+    hipLaunchKernelGGL(mask_overlap_finalize_kernel, dim3(1), dim3(64), 0, s, part, nblk, counts);
+    return check_launch("mask_overlap");
 }

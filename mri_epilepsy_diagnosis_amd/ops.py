@@ -733,6 +733,38 @@ def argmax_mask(logits):
     return out
 
 
+def mask_overlap_counts(pred, gt):
+    """Exact overlap counts of two uint8 masks on the device -> int64 tensor
+    [sum(gt), sum(pred), sum(gt & pred), #(gt>0 & pred>0), #(gt>0 | pred>0)]  (validate_dsc_asd's Dice / IoU inputs,
+    segmentation/routine.py:198-235, metrics.py:312-329)."""
+    for t in (pred, gt):
+        if not t.is_cuda:
+            raise RuntimeError("mask_overlap_counts runs only on ROCm device tensors (got %s); there is no CPU fallback" % t.device)
+        if t.dtype != torch.uint8:
+            raise RuntimeError("mask_overlap_counts: masks must be uint8, got %s" % t.dtype)
+    if pred.shape != gt.shape:
+        raise RuntimeError("mask_overlap_counts: shapes differ %s vs %s" % (tuple(pred.shape), tuple(gt.shape)))
+    L = _lib.lib()
+    pred, gt = pred.contiguous(), gt.contiguous()
+    out = torch.empty(5, dtype=torch.int64, device=pred.device)
+    ws = _workspace(L.mri3d_mask_overlap_workspace_bytes(), pred.device)
+    check(L.mri3d_mask_overlap(_ptr(pred), _ptr(gt), pred.numel(), _ptr(out), _ptr(ws), ws.numel(), _stream()),
+          "mask_overlap")
+    return out
+
+
+def dice_iou_from_counts(counts):
+    """(Dice, IoU) floats with the reference's arithmetic: 2*|gt&pred| / (|gt|+|pred|), NaN if both masks are empty
+    (metrics.py:323-329); intersection / union as Python floats (routine.py:198-203; ZeroDivisionError if both empty)."""
+    import numpy as np
+    sg, sp, sand, n_and, n_or = (int(v) for v in counts.tolist())
+    dsc = float("nan") if sg + sp == 0 else 2 * sand / (sg + sp)
+    # the reference sums float32 indicator arrays and divides `float(intersection) / union` with union an np.float32:
+    # the same expression on the (exactly representable up to 2^24 voxels) counts
+    intersection, union = np.float32(n_and), np.float32(n_or)
+    return dsc, float(intersection) / union
+
+
 # ----------------------------------------------------------------------------------------------- cat / add
 
 

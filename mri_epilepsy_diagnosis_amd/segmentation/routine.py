@@ -91,8 +91,14 @@ def validate_dsc_asd(model, loader, surface_metrics=None):
         with torch.no_grad():
             logits = forward(model, inputs)
         labels = ops.argmax_mask(logits)  # (N, D, H, W) uint8 on device: no logits D2H
-        prediction = labels[0].cpu().numpy()
-        d, am, asd, i = calculate_metrics(targets.cpu().numpy().astype(np.uint8)[0][0], prediction, surface_metrics)
+        if surface_metrics is None and targets.is_cuda:
+            # Dice / IoU from exact integer overlap counts taken on the device: 40 bytes cross PCIe instead of two volumes
+            gt = targets[0][0].to(torch.uint8)      # .astype(np.uint8) of the reference
+            d, i = ops.dice_iou_from_counts(ops.mask_overlap_counts(labels[0], gt))
+            am = asd = float("nan")
+        else:
+            prediction = labels[0].cpu().numpy()
+            d, am, asd, i = calculate_metrics(targets.cpu().numpy().astype(np.uint8)[0][0], prediction, surface_metrics)
         dsc.append(d), asd_mean.append(am), asd_std.append(asd), iou.append(i)
     return dsc, asd_mean, asd_std, iou
 

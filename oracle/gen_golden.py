@@ -240,5 +240,41 @@ def main():
     print("unet ok", traj)
 
 
+def mask_metrics():
+    """tests/golden/mask_metrics.npz: compute_dice_coefficient (segmentation/metrics.py:312-329) and get_iou_score
+    (segmentation/routine.py:198-203) of the REFERENCE on seeded masks; the oracle restatement must agree exactly."""
+    import ast
+    import importlib.util
+    from oracle import metrics as O_MET
+    spec = importlib.util.spec_from_file_location("ref_metrics", os.path.join(REF, "segmentation", "metrics.py"))
+    R_MET = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(R_MET)
+    src = open(os.path.join(REF, "segmentation", "routine.py")).read()
+    fn = [n for n in ast.parse(src).body if isinstance(n, ast.FunctionDef) and n.name == "get_iou_score"][0]
+    ns = {"np": np}
+    exec(compile(ast.Module(body=[fn], type_ignores=[]), "routine_get_iou_score", "exec"), ns)
+    ref_iou = ns["get_iou_score"]
+    cases = [(11, (16, 16, 16), 0.3, 0.3, 0.9), (12, (40, 48, 40), 0.1, 0.12, 0.8), (13, (33, 17, 29), 0.5, 0.05, 0.5),
+             (14, (64, 64, 64), 0.02, 0.02, 0.95), (15, (7, 5, 3), 0.9, 0.9, 0.1)]
+    dsc, iou = [], []
+    for seed, shape, pg, pp, corr in cases:
+        gt, pred = O_MET.seeded_masks(seed, shape, pg, pp, corr)
+        d, i = R_MET.compute_dice_coefficient(gt, pred), ref_iou(pred, gt)
+        assert d == O_MET.dice_coefficient(gt, pred) and i == O_MET.iou_score(pred, gt)
+        dsc.append(d), iou.append(i)
+    # SURVEY Appendix D known answer: 16^3 cubes offset by 2 voxels -> Dice 0.875
+    a = np.zeros((32, 32, 32), np.uint8); a[4:20, 4:20, 4:20] = 1
+    b = np.zeros((32, 32, 32), np.uint8); b[6:22, 4:20, 4:20] = 1
+    assert R_MET.compute_dice_coefficient(a, b) == 0.875
+    np.savez(os.path.join(OUT, "mask_metrics.npz"), cases=np.array([(c[0],) + c[1] for c in cases]),
+             probs=np.array([c[2:] for c in cases]), dice=np.array(dsc), iou=np.array(iou),
+             cube_dice=np.array(R_MET.compute_dice_coefficient(a, b)), cube_iou=np.array(ref_iou(b, a)))
+    print("mask metrics ok", dsc, iou)
+
+
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == "mask_metrics":
+        mask_metrics()
+    else:
+        main()
+        mask_metrics()

@@ -372,3 +372,26 @@ def test_captured_step_replays_eager_step_bit_exactly(bf16):
         assert torch.equal(g_g, flat.grad)
         assert torch.equal(rm_g, net.encoder.encoding_blocks[0].conv2.norm_layer.running_mean)
     assert g_g.abs().max().item() > 0
+
+
+def test_validate_dsc_asd_device_counts_equal_host_metrics():
+    """validate_dsc_asd (segmentation/routine.py:217-237): Dice / IoU from the on-device overlap counts must equal the
+    reference's host arithmetic on the downloaded masks, sample by sample, with the shipped checkpoint's predictions."""
+    from oracle import metrics as O_MET
+    net = _unet(8)
+    net.load_state_dict(load_ckpt("whole_im_train_seg_parc_epoch_7.pth"))
+    net.to(DEV)
+    loader = routine.synthetic_loader(3, 1, (32, 48, 32), seed=5, foreground=0.3)
+    dsc, asd_mean, asd_std, iou = routine.validate_dsc_asd(net, loader)
+    assert len(dsc) == 3 and all(np.isnan(a) for a in asd_mean)
+    net.eval()
+    for k, batch in enumerate(routine.synthetic_loader(3, 1, (32, 48, 32), seed=5, foreground=0.3)):
+        with torch.no_grad():
+            pred = ops.argmax_mask(net(batch[routine.MRI][routine.DATA].to(DEV)))[0].cpu().numpy()
+        gt = batch[routine.LABEL][routine.DATA].numpy().astype(np.uint8)[0][0]
+        assert dsc[k] == O_MET.dice_coefficient(gt, pred)
+        assert iou[k] == O_MET.iou_score(pred, gt)
+    # the host path (surface metrics requested) gives the same Dice / IoU
+    d2, _, _, i2 = routine.validate_dsc_asd(net, routine.synthetic_loader(3, 1, (32, 48, 32), seed=5, foreground=0.3),
+                                            surface_metrics=lambda s, p: (0.0, 0.0))
+    assert d2 == dsc and i2 == iou

@@ -353,3 +353,33 @@ def test_unsupported_and_invalid_arguments_raise():
         ops.conv3d(x.half(), torch.randn(2, 4, 3, 3, 3, device=DEV).half())
     with pytest.raises(RuntimeError):
         ops.softmax_dice_loss(x, _dev(torch.zeros(1, 2, 4, 4, 4), False))
+
+
+def test_mask_overlap_counts_dice_iou_exact():
+    """§8(f1): Dice / IoU of the validation loop from integer overlap counts taken on the device — bit-exact against the
+    oracle (and through it the reference's compute_dice_coefficient / get_iou_score golden values)."""
+    import numpy as np
+    from oracle import metrics as O_MET
+    from util import load_golden
+    g = load_golden("mask_metrics.npz")
+    for row, pr, d, i in zip(g["cases"], g["probs"], g["dice"], g["iou"]):
+        gt, pred = O_MET.seeded_masks(int(row[0]), tuple(int(v) for v in row[1:]), *[float(v) for v in pr])
+        c = ops.mask_overlap_counts(torch.from_numpy(pred).cuda(), torch.from_numpy(gt).cuda())
+        assert c.tolist() == [int(gt.sum()), int(pred.sum()), int((gt & pred).sum()),
+                              int(np.logical_and(gt > 0, pred > 0).sum()), int(np.logical_or(gt > 0, pred > 0).sum())]
+        dsc, iou = ops.dice_iou_from_counts(c)
+        assert dsc == d and iou == i
+    # general uint8 values (label ids), unaligned views, ragged size
+    rng = np.random.Generator(np.random.PCG64(5))
+    gt = rng.integers(0, 256, size=100003, dtype=np.uint8)
+    pred = rng.integers(0, 4, size=100003, dtype=np.uint8)
+    c = ops.mask_overlap_counts(torch.from_numpy(pred).cuda()[3:], torch.from_numpy(gt).cuda()[3:])
+    gt, pred = gt[3:], pred[3:]
+    assert c.tolist() == [int(gt.sum(dtype=np.int64)), int(pred.sum(dtype=np.int64)), int((gt & pred).sum(dtype=np.int64)),
+                          int(np.logical_and(gt > 0, pred > 0).sum()), int(np.logical_or(gt > 0, pred > 0).sum())]
+    # full-size volume (BASELINE shape) against numpy
+    gt, pred = O_MET.seeded_masks(77, (160, 192, 160), 0.1, 0.1, 0.9)
+    dsc, iou = ops.dice_iou_from_counts(ops.mask_overlap_counts(torch.from_numpy(pred).cuda(), torch.from_numpy(gt).cuda()))
+    assert dsc == O_MET.dice_coefficient(gt, pred) and iou == O_MET.iou_score(pred, gt)
+    z = torch.zeros(4, 4, 4, dtype=torch.uint8, device="cuda")
+    assert ops.mask_overlap_counts(z, z).tolist() == [0, 0, 0, 0, 0]    # both empty: Dice is NaN in the reference

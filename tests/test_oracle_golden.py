@@ -161,3 +161,21 @@ def test_reference_gradients_are_discontinuous_at_fp32_noise_level():
         worst[eps] = max(((g1[k] - g0[k]).abs().max() / g0[k].abs().max()).item() for k in g0)
     assert worst[1e-7] < 1e-5
     assert worst[1e-6] > 1e-3
+
+
+def test_mask_metrics_oracle_matches_reference_golden():
+    """oracle.metrics (Dice / IoU of uint8 masks) against values recorded from the reference's own
+    compute_dice_coefficient / get_iou_score (tests/golden/mask_metrics.npz, oracle/gen_golden.py mask_metrics)."""
+    import numpy as np
+    from oracle import metrics as O_MET
+    from util import load_golden
+    g = load_golden("mask_metrics.npz")
+    for row, pr, d, i in zip(g["cases"], g["probs"], g["dice"], g["iou"]):
+        gt, pred = O_MET.seeded_masks(int(row[0]), tuple(int(v) for v in row[1:]), *[float(v) for v in pr])
+        assert O_MET.dice_coefficient(gt, pred) == d
+        assert O_MET.iou_score(pred, gt) == i
+    a = np.zeros((32, 32, 32), np.uint8); a[4:20, 4:20, 4:20] = 1
+    b = np.zeros((32, 32, 32), np.uint8); b[6:22, 4:20, 4:20] = 1
+    assert O_MET.dice_coefficient(a, b) == 0.875 == float(g["cube_dice"])      # SURVEY Appendix D known answer
+    assert O_MET.iou_score(b, a) == g["cube_iou"]
+    assert np.isnan(O_MET.dice_coefficient(np.zeros((4, 4, 4), np.uint8), np.zeros((4, 4, 4), np.uint8)))
