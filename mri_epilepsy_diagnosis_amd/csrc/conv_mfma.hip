@@ -1233,6 +1233,162 @@ conv_mfma_wgrad_bf16_kernel(const bf16_t* __restrict__ x, const bf16_t* __restri
     for (int i = tid; i < TGA * 256; i += 256) out[i] = red[i];
 }
 
+// ------------------------------------------------------------------ weight gradient, version 6 (fp32, Cin % 16 == 0)
+// The bf16 kernel's [channel][voxel] LDS tile, for fp32: a (row, channel) line holds 16 voxels (64 B) + the two W-halo
+// voxels, and the MFMA K order is permuted so that k-group kq of the four k-steps of a row owns voxels 4kq..4kq+3 — ONE
+// ds_read_b128 then feeds four v_mfma_f32_16x16x4_f32 k-steps, and the kw = 0 / 2 taps are the same fragment shifted by one
+// voxel, i.e. pure register selection from (left neighbour, fragment, right neighbour).  A 2x6x16-voxel tile costs a wave
+// 3 rows x (1 + 9 x 3) = 84 LDS reads for 324 MFMAs; v4 issues one 4-byte LDS read per MFMA, and every non-MFMA
+// instruction shows up as idle MFMA time (ablation in DESIGN.md §4.1).  Staging transposes 4 voxels x 4 channels per
+// lane by register renaming.  Same accumulators and partial layout as v4.
+constexpr int FTW = 16;   // voxels per line
+
+template <bool BIAS>
+__global__ void __launch_bounds__(256, 2)
+conv_mfma_wgrad6_kernel(const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ part, int N, int D,
+                        int H, int W, int Ci, int x_ld, int Co, int y_ld, int tilesD, int tilesH, int tilesW, int ntiles) {
+    constexpr int TG = 27, TGA = TG + (BIAS ? 1 : 0);
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    char* xs = reinterpret_cast<char*>(lds);
+    char* ys = xs + BXS;
+
+    const int cit = blockIdx.y, cob = blockIdx.z;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int li = lane & 15, kq = lane >> 4;
+
+    f32x4 acc[TGA];
+#pragma unroll
+    for (int t = 0; t < TGA; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // staging roles: a unit = 4 consecutive voxels x 4 channels; X has 32 rows x 4 w-groups x 4 quads = 512 units (2 per
+    // lane), its halo 32 rows x 2 sides x 4 quads = 256 (1 per lane), dY 12 rows x 4 x 4 = 192 units (lanes < 192)
+    const int s_q = tid & 3, s_wg = (tid >> 2) & 3, s_row = tid >> 4;      // unit u = tid (+256): row = s_row (+16)
+    const int h_q = tid & 3, h_side = (tid >> 2) & 1, h_row = tid >> 3;
+    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    const int p_off = kq == 0 ? 64 : 16 * kq - 4, n_off = kq == 3 ? 68 : 16 * kq + 16;
+
+    // next tile's pieces: fetched into registers while the current tile is multiplied (HBM/L2 latency hidden), written to
+    // the single LDS tile between two barriers after it
+    float4 vx[2][4], vh, vy[4];
+    auto load_tile = [&](int tile) {
+        const int w0 = (tile % tilesW) * FTW;
+        tile /= tilesW;
+        const int h0 = (tile % tilesH) * BTH;
+        tile /= tilesH;
+        const int d0 = (tile % tilesD) * BTD;
+        const int n = tile / tilesD;
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {   // ---- X
+            const int row = s_row + 16 * u;
+            const int gd = d0 - 1 + row / BHH, gh = h0 - 1 + row % BHH;
+            const bool rok = (unsigned)gd < (unsigned)D && (unsigned)gh < (unsigned)H;
+            const float* src = x + ((((int64_t)n * D + (rok ? gd : 0)) * H + (rok ? gh : 0)) * W) * x_ld + cit * 16 + 4 * s_q;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int gw = w0 + 4 * s_wg + j;
+                vx[u][j] = (rok && gw < W) ? *reinterpret_cast<const float4*>(src + (int64_t)gw * x_ld) : zero4;
+            }
+        }
+        {   // ---- X halo voxels
+            const int gd = d0 - 1 + h_row / BHH, gh = h0 - 1 + h_row % BHH, gw = h_side ? w0 + FTW : w0 - 1;
+            const bool ok = (unsigned)gd < (unsigned)D && (unsigned)gh < (unsigned)H && (unsigned)gw < (unsigned)W;
+            vh = zero4;
+            if (ok) vh = *reinterpret_cast<const float4*>(x + ((((int64_t)n * D + gd) * H + gh) * W + gw) * x_ld + cit * 16 + 4 * h_q);
+        }
+        if (tid < BYR * 16) {   // ---- dY
+            const int gd = d0 + s_row / BTH, gh = h0 + s_row % BTH;
+            const int c0 = cob * 16 + 4 * s_q;
+            const bool rok = gd < D && gh < H && c0 < Co;       // host guarantees Co % 4 == 0
+            const float* src = dy + ((((int64_t)n * D + (rok ? gd : 0)) * H + (rok ? gh : 0)) * W) * y_ld + (c0 < Co ? c0 : 0);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int gw = w0 + 4 * s_wg + j;
+                vy[j] = (rok && gw < W) ? *reinterpret_cast<const float4*>(src + (int64_t)gw * y_ld) : zero4;
+            }
+        }
+    };
+    auto store_tile = [&]() {
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            char* dst = xs + ((s_row + 16 * u) * 16 + 4 * s_q) * BRS + 16 * s_wg;
+            *reinterpret_cast<float4*>(dst) = make_float4(vx[u][0].x, vx[u][1].x, vx[u][2].x, vx[u][3].x);
+            *reinterpret_cast<float4*>(dst + BRS) = make_float4(vx[u][0].y, vx[u][1].y, vx[u][2].y, vx[u][3].y);
+            *reinterpret_cast<float4*>(dst + 2 * BRS) = make_float4(vx[u][0].z, vx[u][1].z, vx[u][2].z, vx[u][3].z);
+            *reinterpret_cast<float4*>(dst + 3 * BRS) = make_float4(vx[u][0].w, vx[u][1].w, vx[u][2].w, vx[u][3].w);
+        }
+        {
+            char* dst = xs + (h_row * 16 + 4 * h_q) * BRS + 64 + 4 * h_side;
+            *reinterpret_cast<float*>(dst) = vh.x;
+            *reinterpret_cast<float*>(dst + BRS) = vh.y;
+            *reinterpret_cast<float*>(dst + 2 * BRS) = vh.z;
+            *reinterpret_cast<float*>(dst + 3 * BRS) = vh.w;
+        }
+        if (tid < BYR * 16) {
+            char* dst = ys + (s_row * 16 + 4 * s_q) * BRS + 16 * s_wg;
+            *reinterpret_cast<float4*>(dst) = make_float4(vy[0].x, vy[1].x, vy[2].x, vy[3].x);
+            *reinterpret_cast<float4*>(dst + BRS) = make_float4(vy[0].y, vy[1].y, vy[2].y, vy[3].y);
+            *reinterpret_cast<float4*>(dst + 2 * BRS) = make_float4(vy[0].z, vy[1].z, vy[2].z, vy[3].z);
+            *reinterpret_cast<float4*>(dst + 3 * BRS) = make_float4(vy[0].w, vy[1].w, vy[2].w, vy[3].w);
+        }
+    };
+
+    const TileWalk tw = tile_walk(ntiles);
+    if (tw.count > 0) load_tile(tw.first);
+    for (int k = 0; k < tw.count; ++k) {
+        __syncthreads();   // the previous tile's MFMAs are done with the LDS tile
+        store_tile();
+        __syncthreads();
+        if (k + 1 < tw.count) load_tile(tw.first + (k + 1) * tw.stride);
+        __builtin_amdgcn_sched_barrier(0);
+
+        // ---- 3 output rows per wave x 9 (kd, kh) x 3 kw x 4 k-steps
+#pragma unroll 1
+        for (int r = 0; r < BYR / 4; ++r) {
+            const int orow = wv * (BYR / 4) + r;
+            const int dz = orow / BTH, hy = orow % BTH;
+            const float4 b = *reinterpret_cast<const float4*>(ys + (orow * 16 + li) * BRS + 16 * kq);
+            const float bk[4] = {b.x, b.y, b.z, b.w};
+            if (BIAS) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[TG] = __builtin_amdgcn_mfma_f32_16x16x4f32(1.0f, bk[j], acc[TG], 0, 0, 0);
+            }
+#pragma unroll
+            for (int kdh = 0; kdh < 9; ++kdh) {
+                const int xr = (dz + kdh / 3) * BHH + hy + kdh % 3;
+                const char* base = xs + (xr * 16 + li) * BRS;
+                const float4 g = *reinterpret_cast<const float4*>(base + 16 * kq);
+                const float pp = *reinterpret_cast<const float*>(base + p_off);
+                const float nn = *reinterpret_cast<const float*>(base + n_off);
+                const float a0[4] = {pp, g.x, g.y, g.z}, a1[4] = {g.x, g.y, g.z, g.w}, a2[4] = {g.y, g.z, g.w, nn};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    acc[kdh * 3 + 0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[j], bk[j], acc[kdh * 3 + 0], 0, 0, 0);
+                    acc[kdh * 3 + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[j], bk[j], acc[kdh * 3 + 1], 0, 0, 0);
+                    acc[kdh * 3 + 2] = __builtin_amdgcn_mfma_f32_16x16x4f32(a2[j], bk[j], acc[kdh * 3 + 2], 0, 0, 0);
+                }
+            }
+        }
+    }
+
+    // combine the 4 waves in a fixed order through LDS, then one partial per workgroup
+    __syncthreads();
+    float* red = lds;  // [TGA][256]
+    for (int w = 0; w < 4; ++w) {
+        if (wv == w) {
+#pragma unroll
+            for (int t = 0; t < TGA; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int o = t * 256 + (4 * kq + r) * 16 + li;
+                    red[o] = (w == 0) ? acc[t][r] : red[o] + acc[t][r];
+                }
+        }
+        __syncthreads();
+    }
+    float* out = part + (((size_t)blockIdx.x * gridDim.y + cit) * gridDim.z + cob) * (TGA * 256);
+    for (int i = tid; i < TGA * 256; i += 256) out[i] = red[i];
+}
+
 // dw[co][ci][tap] = sum_p part[p][cit][cob][tg][row][col]   (+ dbias[co] from the extra accumulator of cit == 0)
 // Threads walk the partial layout itself (64 consecutive elements per wave => coalesced 256-byte reads of every
 // partial), 4 partial-lanes per element combined through LDS in double; the (tiny) result is scattered into torch's
@@ -1285,6 +1441,10 @@ static bool mfma_wgrad_plan(const Mri3dConvGeom& g, MfmaWgradPlan& p) {
     p.v2 = (!use_v1 && g.ci % 8 == 0 && g.co % 4 == 0 && g.y_ld % 4 == 0) ? (g.ci % 16 == 0 ? 2 : 1) : 0;
     static const int no_bf = getenv("MRI3D_WGRAD_BF16_OFF") ? atoi(getenv("MRI3D_WGRAD_BF16_OFF")) : 0;   // tuning aid (A/B)
     if (g.dtype == MRI3D_BF16 && !no_bf && g.ci % 8 == 0 && g.co % 8 == 0 && g.x_ld % 8 == 0 && g.y_ld % 8 == 0) p.v2 = 3;
+    // 4 = v6 (fp32 transposed-tile kernel).  Measured on MI355X: v6 wins where v4's interior-tile fast path covers few
+    // tiles (W = 80: 96->32 97.0 vs 89.5, 32->32 94.3 vs 89.9 TFLOP/s), v4 at W = 160 (48->16 102.7 vs 101.8).
+    static const int force_v6 = getenv("MRI3D_WGRAD_V6") ? atoi(getenv("MRI3D_WGRAD_V6")) : -1;   // tuning aid (A/B): 0 / 1
+    if (p.v2 == 2 && g.dtype == MRI3D_F32 && (force_v6 < 0 ? g.wi < 128 : force_v6 != 0)) p.v2 = 4;
     if (p.v2 == 3) p.CK = 16;
     else if (g.ci % 16 == 0) p.CK = 16;
     else if (g.ci % 8 == 0) p.CK = 8;
@@ -1294,9 +1454,9 @@ static bool mfma_wgrad_plan(const Mri3dConvGeom& g, MfmaWgradPlan& p) {
     p.CIT = cdiv(g.ci, p.CK);
     p.COB = cdiv(g.co, 16);
     p.TG = wg_tap_groups(p.CK);
-    p.tilesD = cdiv(g.di, p.v2 == 3 ? BTD : WTD);
-    p.tilesH = cdiv(g.hi, p.v2 == 3 ? BTH : (p.v2 == 2 ? V4TH : WTH));
-    p.tilesW = cdiv(g.wi, p.v2 == 3 ? BTW : WTW);
+    p.tilesD = cdiv(g.di, p.v2 >= 3 ? BTD : WTD);
+    p.tilesH = cdiv(g.hi, p.v2 >= 3 ? BTH : (p.v2 == 2 ? V4TH : WTH));
+    p.tilesW = cdiv(g.wi, p.v2 == 3 ? BTW : (p.v2 == 4 ? FTW : WTW));
     int64_t nt = (int64_t)g.n * p.tilesD * p.tilesH * p.tilesW;
     if (nt > 0x7fffffff) return false;
     p.ntiles = (int)nt;
@@ -1316,7 +1476,7 @@ static bool mfma_wgrad_plan(const Mri3dConvGeom& g, MfmaWgradPlan& p) {
         p.smem = std::max<size_t>(xbuf + (size_t)WVOX * 16, red) * sizeof(float);
     } else if (p.v2 == 2) {
         p.smem = std::max<size_t>((size_t)2 * V4XBUF + 2 * V4YBUF, red) * sizeof(float);
-    } else if (p.v2 == 3) {
+    } else if (p.v2 >= 3) {
         p.smem = std::max<size_t>((size_t)BXS + BYS, red * sizeof(float));
     }
     return true;
@@ -1377,6 +1537,20 @@ static void run_mfma_wgrad(const MfmaWgradPlan& p, const Mri3dConvGeom& g, const
     }
             if (bias) MRI3D_WGB(true) else MRI3D_WGB(false)
 #undef MRI3D_WGB
+        }
+    } else if (p.v2 == 4) {
+        if constexpr (sizeof(T) == 4) {
+            dim3 grid(p.P, p.CIT, p.COB);
+#define MRI3D_WG6(Bv)                                                                                                 \
+    {                                                                                                                 \
+        auto kern = conv_mfma_wgrad6_kernel<Bv>;                                                                      \
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,   \
+                                  (int)p.smem);                                                                       \
+        hipLaunchKernelGGL(kern, grid, dim3(256), p.smem, s, x, dy, part, g.n, g.di, g.hi, g.wi, g.ci, g.x_ld, g.co,  \
+                           g.y_ld, p.tilesD, p.tilesH, p.tilesW, p.ntiles);                                           \
+    }
+            if (bias) MRI3D_WG6(true) else MRI3D_WG6(false)
+#undef MRI3D_WG6
         }
     } else if (p.v2 == 2) {
         dim3 grid(p.P, p.CIT, p.COB);
