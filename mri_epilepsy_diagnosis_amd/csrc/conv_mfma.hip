@@ -277,6 +277,18 @@ conv_mfma_fwd2_kernel(const T* __restrict__ x, const float* __restrict__ wp, con
         const int wx = v % HW, t2 = v / HW;
         srel[j] = ((t2 / HH) << 16) | ((t2 % HH) << 8) | wx;
     }
+    // ... and its element offset from the tile's halo origin voxel (d0-1, h0-1, w0-1), so that a piece's address is a
+    // wave-uniform base + a 32-bit lane offset: no per-piece integer multiplies, clamps or 64-bit arithmetic (the ISA of
+    // the previous version spent 52 v_mul_lo_u32 + 35 64-bit mads per chunk on them — quarter-rate VALU work that the
+    // fp32 MFMA does not hide).  Out-of-volume pieces read the tile's first output voxel instead (always valid) and are
+    // zeroed when they are written to LDS.
+    unsigned frel[kStg];
+#pragma unroll
+    for (int j = 0; j < kStg; ++j) {
+        const int r = srel[j];
+        frel[j] = (unsigned)((((r >> 16) * H + ((r >> 8) & 0xff)) * W + (r & 0xff)) * x_ld + PE * (tid & 1));
+    }
+    const unsigned forig = (unsigned)(((H + 1) * W + 1) * x_ld);
 
     struct Item { int n, d0, h0, w0, nt0, ch; };
     auto decode = [&](int it) -> Item {
@@ -297,15 +309,23 @@ conv_mfma_fwd2_kernel(const T* __restrict__ x, const float* __restrict__ wp, con
     // three tap groups later.  A load inside a branch makes hipcc treat it as "maybe not issued" and shorten every
     // later vmcnt wait of the B ring to cover it (12 % measured); zeroing right after the load forces vmcnt(0).
     unsigned okmask = 0;
-    auto stage_load = [&](const Item& it, int j) -> float4 {
+    auto halo_origin = [&](const Item& it) -> const T* {   // wave-uniform; only dereferenced at in-volume offsets
+        return x + (((((int64_t)it.n * D + it.d0 - 1) * H + it.h0 - 1) * W + it.w0 - 1) * x_ld + it.ch * CK);
+    };
+    auto stage_load = [&](const Item& it, const T* fb, int j) -> float4 {
         const int r = srel[j];
         const int gd = it.d0 - 1 + (r >> 16), gh = it.h0 - 1 + ((r >> 8) & 0xff), gw = it.w0 - 1 + (r & 0xff);
-        const int c0 = it.ch * CK + PE * (tid & 1);
-        const bool ok = (unsigned)gd < (unsigned)D && (unsigned)gh < (unsigned)H && (unsigned)gw < (unsigned)W && c0 < Kc;
+        const bool ok = (unsigned)gd < (unsigned)D && (unsigned)gh < (unsigned)H && (unsigned)gw < (unsigned)W &&
+                        it.ch * CK + PE * (tid & 1) < Kc;
         okmask = ok ? (okmask | (1u << j)) : (okmask & ~(1u << j));
-        const int cd = min(max(gd, 0), D - 1), chh = min(max(gh, 0), H - 1), cw = min(max(gw, 0), W - 1);
-        return *reinterpret_cast<const float4*>(x + ((((int64_t)it.n * D + cd) * H + chh) * W + cw) * x_ld +
-                                                (c0 < Kc ? c0 : 0));
+        if constexpr (NT == 1) {
+            return *reinterpret_cast<const float4*>(fb + (ok ? frel[j] : forig));
+        } else {   // NT = 2 has no 9 registers to spare for frel (it spills): clamped coordinates, 64-bit address arithmetic
+            const int c0 = it.ch * CK + PE * (tid & 1);
+            const int cd = min(max(gd, 0), D - 1), chh = min(max(gh, 0), H - 1), cw = min(max(gw, 0), W - 1);
+            return *reinterpret_cast<const float4*>(x + ((((int64_t)it.n * D + cd) * H + chh) * W + cw) * x_ld +
+                                                    (c0 < Kc ? c0 : 0));
+        }
     };
     auto stage_store = [&](float* buf, int j, const float4& val) {
         const bool ok = (okmask >> j) & 1u;
@@ -322,7 +342,7 @@ conv_mfma_fwd2_kernel(const T* __restrict__ x, const float* __restrict__ wp, con
     {
         float4 tmp[kStg];
 #pragma unroll
-        for (int j = 0; j < kStg; ++j) tmp[j] = stage_load(cur, j);
+        for (int j = 0; j < kStg; ++j) tmp[j] = stage_load(cur, halo_origin(cur), j);
 #pragma unroll
         for (int j = 0; j < kStg; ++j) stage_store(lds, j, tmp[j]);
     }
@@ -348,6 +368,7 @@ conv_mfma_fwd2_kernel(const T* __restrict__ x, const float* __restrict__ wp, con
         const bool has_next = it + 1 < nitems;
         Item nxt = cur;
         if (has_next) nxt = decode(it + 1);
+        const T* fbn = halo_origin(nxt);
 
         const float* wt = wp + ((size_t)cur.ch * TG * NTT + cur.nt0) * 256 + lane * 4;
         const size_t wstep = (size_t)NTT * 256;
@@ -367,7 +388,7 @@ conv_mfma_fwd2_kernel(const T* __restrict__ x, const float* __restrict__ wp, con
 #pragma unroll
         for (int tg = 0; tg < TG; ++tg) {
             const int cb = tg % 3, nb = (tg + 2) % 3, ac = tg & 1, an = (tg + 1) & 1;
-            if (tg < kStg) sq[tg & 3] = stage_load(nxt, tg);  // next chunk: global -> regs (unconditional)
+            if (tg < kStg) sq[tg & 3] = stage_load(nxt, fbn, tg);  // next chunk: global -> regs (unconditional)
             if (tg + 2 < TG) {
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt)
