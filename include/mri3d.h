@@ -175,6 +175,23 @@ int mri3d_mask_overlap(const uint8_t* pred, const uint8_t* gt, int64_t nvox, int
                        size_t ws_bytes, mri3d_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * Intensity standardisation ahead of the path: the reference's collate function runs `normalize`
+ * (classification/train_ENC_CLF.ipynb cell 9) on every volume — np.percentile at 13 percentiles over all voxels, then a
+ * piecewise-linear map between landmarks evaluated in float64.
+ *   order_stats: out[i] = the ranks[i]-th smallest element (0-based) of x[0..n); ranks is a HOST array of nranks <= 32.
+ *                Exact (integer radix histograms).  np.percentile's linear interpolation between two neighbouring order
+ *                statistics is left to the caller (13 float64 operations).
+ *   piecewise_linear: y = (float)(slope[b] * (double)x + intercept[b]), b = #{e : edges[e] <= x} (np.digitize, right=False),
+ *                multiply and add rounded separately as numpy does; edges / slope / intercept are HOST arrays,
+ *                nseg <= 16 segments, nseg-1 non-decreasing edges.
+ * ---------------------------------------------------------------------------------------------- */
+size_t mri3d_order_stats_workspace_bytes(void);
+int mri3d_order_stats_f32(const float* x, int64_t n, const int64_t* ranks, int32_t nranks, float* out, void* workspace,
+                          size_t ws_bytes, mri3d_stream_t stream);
+int mri3d_piecewise_linear_f32(const float* x, float* y, int64_t n, const double* edges, const double* slope,
+                               const double* intercept, int32_t nseg, mri3d_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Channel-slice plumbing: torch.cat along channels (unet.UNet decoder, modified_3dunet.py:158-178) and
  * residual adds (modified_3dunet.py:108, cnn_model.py:34).
  *   copy: dst[v, 0:c] = src[v, 0:c]      add: dst[v, 0:c] = a[v,0:c] + b[v,0:c]

@@ -1,0 +1,172 @@
+// preprocess.hip — intensity standardisation ahead of the conv path: the histogram standardisation the
+// reference applies in its collate function (`normalize`, classification/train_ENC_CLF.ipynb cell 9: np.percentile over the
+// whole volume at 13 percentiles, then an 10-segment piecewise-linear map in float64) — in the reference this is
+// np.percentile + np.digitize over ~5-7 M voxels per volume on one CPU core per sample.
+//
+//   mri3d_order_stats_f32     exact order statistics x_(r) for up to 32 ranks of an fp32 array: three radix passes
+//                             (11 + 11 + 10 key bits) of integer histograms.  Integer atomics only, so the result is exact
+//                             and run-to-run identical; np.percentile's linear interpolation between two neighbouring order
+//                             statistics is then 13 float64 operations on the host, bit-identical to numpy's _lerp.
+//   mri3d_piecewise_linear_f32  y = float32(slope[b] * double(x) + intercept[b]),  b = #(edges <= x)  (np.digitize, right=False),
+//                             with separately rounded multiply and add like numpy's `lin_img * data + aff_img`.
+// Both are HBM-bound streams (4 B/voxel read per radix pass; 8 B/voxel for the map).
+#include "common.h"
+#include <algorithm>
+
+namespace mri3d {
+
+constexpr int kMaxRanks = 32;
+constexpr int kB0 = 2048, kB1 = 2048, kB2 = 1024;   // bins of the three radix levels: key bits [31:21], [20:10], [9:0]
+
+struct RankSet { long long rank[kMaxRanks]; int n; };
+struct PwlMap { double edge[16]; double slope[16]; double icpt[16]; int nseg; };
+
+// order-preserving key: ascending unsigned order == ascending float order (-0.0 sorts just below +0.0, NaN payloads last)
+__device__ __forceinline__ unsigned f32_key(float f) {
+    const unsigned u = __float_as_uint(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float key_f32(unsigned k) {
+    const unsigned u = (k & 0x80000000u) ? (k & 0x7fffffffu) : ~k;
+    return __uint_as_float(u);
+}
+
+// state layout in the workspace (all unsigned 32-bit unless noted):
+//   hist0[kB0] | hist1[R][kB1] | hist2[R][kB2] | prefix[R] | remaining[R] (u64)
+__global__ void __launch_bounds__(256)
+ostat_hist0_kernel(const float* __restrict__ x, long long n, unsigned* __restrict__ hist0) {
+    __shared__ unsigned h[kB0];
+    for (int i = threadIdx.x; i < kB0; i += blockDim.x) h[i] = 0u;
+    __syncthreads();
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+        atomicAdd(&h[f32_key(x[i]) >> 21], 1u);
+    __syncthreads();
+    for (int i = threadIdx.x; i < kB0; i += blockDim.x)
+        if (h[i]) atomicAdd(&hist0[i], h[i]);
+}
+
+// level 1 / 2: only elements whose leading bits equal some rank's prefix are counted (about R/2048 of the data), straight
+// into global memory
+template <int LEVEL>
+__global__ void __launch_bounds__(256)
+ostat_hist_kernel(const float* __restrict__ x, long long n, const unsigned* __restrict__ prefix, unsigned* __restrict__ hist,
+                  int R) {
+    __shared__ unsigned pf[kMaxRanks];
+    if (threadIdx.x < R) pf[threadIdx.x] = prefix[threadIdx.x];
+    __syncthreads();
+    constexpr int SH = LEVEL == 1 ? 21 : 10;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const unsigned k = f32_key(x[i]);
+        const unsigned top = k >> SH;
+        for (int r = 0; r < R; ++r) {   // ranks sharing a prefix share the histogram row of the first of them
+            if (pf[r] == top) {
+                if (LEVEL == 1) atomicAdd(&hist[(size_t)r * kB1 + ((k >> 10) & 0x7ffu)], 1u);
+                else atomicAdd(&hist[(size_t)r * kB2 + (k & 0x3ffu)], 1u);
+                break;
+            }
+        }
+    }
+}
+
+// one thread per rank walks its histogram row: bin whose cumulative count passes `remaining`
+template <int LEVEL>
+__global__ void ostat_select_kernel(RankSet rs, const unsigned* __restrict__ hist, unsigned* __restrict__ prefix,
+                                    unsigned long long* __restrict__ remaining, float* __restrict__ out) {
+    const int r = threadIdx.x;
+    if (r >= rs.n) return;
+    constexpr int NB = LEVEL == 0 ? kB0 : (LEVEL == 1 ? kB1 : kB2);
+    int row = 0;
+    if (LEVEL > 0) {   // the row of the first rank with the same prefix
+        row = r;
+        for (int q = 0; q < r; ++q)
+            if (prefix[q] == prefix[r]) { row = q; break; }
+    }
+    const unsigned* h = hist + (size_t)row * NB;
+    unsigned long long rem = LEVEL == 0 ? (unsigned long long)rs.rank[r] : remaining[r];
+    int b = 0;
+    for (; b < NB - 1; ++b) {
+        const unsigned c = h[b];
+        if (rem < c) break;
+        rem -= c;
+    }
+    __syncthreads();   // every lane has read the shared prefix table before anyone rewrites it
+    const unsigned np = LEVEL == 0 ? (unsigned)b : ((prefix[r] << (LEVEL == 1 ? 11 : 10)) | (unsigned)b);
+    prefix[r] = np;
+    remaining[r] = rem;
+    if (LEVEL == 2) out[r] = key_f32(np);
+}
+
+__global__ void __launch_bounds__(256)
+pwl_kernel(const float* __restrict__ x, float* __restrict__ y, long long n, PwlMap m) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const double xd = (double)x[i];
+        int b = 0;
+#pragma unroll
+        for (int e = 0; e < 15; ++e) b += (e < m.nseg - 1 && m.edge[e] <= xd) ? 1 : 0;
+        // numpy: lin_img * data (rounded) + aff_img (rounded) — no fused multiply-add
+        y[i] = (float)__dadd_rn(__dmul_rn(m.slope[b], xd), m.icpt[b]);
+    }
+}
+
+}  // namespace mri3d
+
+using namespace mri3d;
+
+extern "C" size_t mri3d_order_stats_workspace_bytes(void) {
+    return (size_t)(kB0 + kMaxRanks * kB1 + kMaxRanks * kB2 + kMaxRanks) * sizeof(unsigned) +
+           (size_t)kMaxRanks * sizeof(unsigned long long) + 64;
+}
+
+extern "C" int mri3d_order_stats_f32(const float* x, int64_t n, const int64_t* ranks, int32_t nranks, float* out,
+                                     void* workspace, size_t ws_bytes, mri3d_stream_t stream) {
+    MRI3D_REQUIRE(x && ranks && out && n > 0 && nranks > 0 && nranks <= kMaxRanks, MRI3D_EINVAL,
+                  "order_stats: bad arguments (n=%lld, nranks=%d, max %d)", (long long)n, nranks, kMaxRanks);
+    MRI3D_REQUIRE(n <= 0xffffffffLL, MRI3D_ENOTSUP, "order_stats: n must fit 32-bit counters");
+    MRI3D_REQUIRE(workspace && ws_bytes >= mri3d_order_stats_workspace_bytes() &&
+                      (reinterpret_cast<uintptr_t>(workspace) & 7) == 0,
+                  MRI3D_EWORKSPACE, "order_stats: workspace %zu < %zu", ws_bytes, mri3d_order_stats_workspace_bytes());
+    RankSet rs;
+    rs.n = nranks;
+    for (int i = 0; i < nranks; ++i) {
+        MRI3D_REQUIRE(ranks[i] >= 0 && ranks[i] < n, MRI3D_EINVAL, "order_stats: rank %lld outside [0, %lld)",
+                      (long long)ranks[i], (long long)n);
+        rs.rank[i] = ranks[i];
+    }
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    unsigned long long* remaining = static_cast<unsigned long long*>(workspace);
+    unsigned* hist0 = reinterpret_cast<unsigned*>(remaining + kMaxRanks);
+    unsigned* hist1 = hist0 + kB0;
+    unsigned* hist2 = hist1 + (size_t)kMaxRanks * kB1;
+    unsigned* prefix = hist2 + (size_t)kMaxRanks * kB2;
+    const size_t zero_bytes = (size_t)(kB0 + kMaxRanks * kB1 + kMaxRanks * kB2 + kMaxRanks) * sizeof(unsigned);
+    if (hipMemsetAsync(hist0, 0, zero_bytes, s) != hipSuccess) {
+        set_error("order_stats: hipMemsetAsync failed");
+        return MRI3D_ELAUNCH;
+    }
+    const int grid = stream_grid(n, 256 * 8);
+    hipLaunchKernelGGL(ostat_hist0_kernel, dim3(grid), dim3(256), 0, s, x, (long long)n, hist0);
+    hipLaunchKernelGGL(ostat_select_kernel<0>, dim3(1), dim3(kMaxRanks), 0, s, rs, hist0, prefix, remaining, out);
+    hipLaunchKernelGGL(ostat_hist_kernel<1>, dim3(grid), dim3(256), 0, s, x, (long long)n, prefix, hist1, nranks);
+    hipLaunchKernelGGL(ostat_select_kernel<1>, dim3(1), dim3(kMaxRanks), 0, s, rs, hist1, prefix, remaining, out);
+    hipLaunchKernelGGL(ostat_hist_kernel<2>, dim3(grid), dim3(256), 0, s, x, (long long)n, prefix, hist2, nranks);
+    hipLaunchKernelGGL(ostat_select_kernel<2>, dim3(1), dim3(kMaxRanks), 0, s, rs, hist2, prefix, remaining, out);
+    return check_launch("order_stats");
+}
+
+extern "C" int mri3d_piecewise_linear_f32(const float* x, float* y, int64_t n, const double* edges, const double* slope,
+                                          const double* intercept, int32_t nseg, mri3d_stream_t stream) {
+    MRI3D_REQUIRE(x && y && slope && intercept && n > 0 && nseg >= 1 && nseg <= 16 && (nseg == 1 || edges), MRI3D_EINVAL,
+                  "piecewise_linear: bad arguments (nseg=%d, max 16)", nseg);
+    PwlMap m;
+    m.nseg = nseg;
+    for (int i = 0; i < 16; ++i) {
+        m.edge[i] = (i < nseg - 1) ? edges[i] : 0.0;
+        m.slope[i] = (i < nseg) ? slope[i] : 0.0;
+        m.icpt[i] = (i < nseg) ? intercept[i] : 0.0;
+    }
+    for (int i = 0; i + 2 < nseg; ++i)
+        MRI3D_REQUIRE(!(edges[i + 1] < edges[i]), MRI3D_EINVAL, "piecewise_linear: edges must be non-decreasing");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    hipLaunchKernelGGL(pwl_kernel, dim3(stream_grid(n, 256 * 4)), dim3(256), 0, s, x, y, (long long)n, m);
+    return check_launch("piecewise_linear");
+}

@@ -272,9 +272,47 @@ def mask_metrics():
     print("mask metrics ok", dsc, iou)
 
 
+def hist_std():
+    """tests/golden/hist_std.npz: the REFERENCE's own `normalize` (classification/train_ENC_CLF.ipynb cell 9, executed from
+    the notebook JSON) on seeded synthetic T1-like volumes with the shipped landmarks and with a synthetic monotone
+    landmark set; the oracle restatement must agree bit for bit.  Stored: seeds/shapes, output checksums and samples."""
+    import json
+    from typing import Tuple  # noqa: F401  (the cell's annotations)
+    from oracle import preprocessing as O_PRE
+    nb = json.load(open(os.path.join(REF, "classification", "train_ENC_CLF.ipynb")))
+    src = "".join(nb["cells"][9]["source"])
+    ns = {"np": np, "torch": torch, "Tuple": Tuple}
+    exec(compile(src, "train_ENC_CLF_cell9", "exec"), ns)
+    ref_normalize = ns["normalize"]
+    shipped = np.load(os.path.join(REF, "segmentation", "weights", "fcd_train_data_landmarks.npy"))
+    shutil.copyfile(os.path.join(REF, "segmentation", "weights", "fcd_train_data_landmarks.npy"),
+                    os.path.join(OUT, "fcd_train_data_landmarks.npy"))
+    mono = np.array([0.0, 4.5, 11.0, 14.2, 17.9, 26.0, 35.5, 47.0, 58.0, 63.1, 69.0, 84.0, 100.0])
+    cases = [(21, (24, 28, 20)), (22, (40, 48, 40)), (23, (17, 9, 31)), (24, (64, 64, 48))]
+    rec = {"cases": np.array([(c[0],) + c[1] for c in cases]), "mono_landmarks": mono}
+    for name, lm in (("shipped", shipped), ("mono", mono)):
+        sums, samples, shas = [], [], []
+        for seed, shape in cases:
+            vol = O_PRE.synthetic_t1(seed, shape)
+            out_r = ref_normalize(torch.from_numpy(vol.copy()), lm).numpy()
+            out_o = O_PRE.normalize(vol, lm)
+            assert out_r.dtype == np.float32 and np.array_equal(out_r, out_o, equal_nan=True), (name, seed)
+            sums.append(float(out_r.astype(np.float64).sum()))
+            samples.append(out_r.reshape(-1)[::max(1, out_r.size // 64)][:64].copy())
+            shas.append(hashlib.sha256(out_r.tobytes()).hexdigest())
+        rec[name + "_sum"] = np.array(sums)
+        rec[name + "_sample"] = np.stack(samples)
+        rec[name + "_sha256"] = np.array(shas)
+    np.savez(os.path.join(OUT, "hist_std.npz"), **rec)
+    print("hist_std ok", rec["mono_sum"], rec["shipped_sum"])
+
+
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "mask_metrics":
         mask_metrics()
+    elif len(sys.argv) > 1 and sys.argv[1] == "hist_std":
+        hist_std()
     else:
         main()
         mask_metrics()
+        hist_std()

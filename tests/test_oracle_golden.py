@@ -179,3 +179,22 @@ def test_mask_metrics_oracle_matches_reference_golden():
     assert O_MET.dice_coefficient(a, b) == 0.875 == float(g["cube_dice"])      # SURVEY Appendix D known answer
     assert O_MET.iou_score(b, a) == g["cube_iou"]
     assert np.isnan(O_MET.dice_coefficient(np.zeros((4, 4, 4), np.uint8), np.zeros((4, 4, 4), np.uint8)))
+
+
+def test_hist_std_oracle_matches_reference_golden():
+    """oracle.preprocessing.normalize against outputs recorded from the reference's own `normalize`
+    (classification/train_ENC_CLF.ipynb cell 9, executed by oracle/gen_golden.py hist_std): bit-exact (sha256)."""
+    import hashlib
+    import numpy as np
+    from oracle import preprocessing as O_PRE
+    from util import GOLDEN, load_golden
+    import os
+    g = load_golden("hist_std.npz")
+    shipped = np.load(os.path.join(GOLDEN, "fcd_train_data_landmarks.npy"))
+    for name, lm in (("shipped", shipped), ("mono", g["mono_landmarks"])):
+        for i, row in enumerate(g["cases"]):
+            vol = O_PRE.synthetic_t1(int(row[0]), tuple(int(v) for v in row[1:]))
+            out = O_PRE.normalize(vol, lm)
+            assert out.dtype == np.float32
+            assert hashlib.sha256(out.tobytes()).hexdigest() == str(g[name + "_sha256"][i]), (name, i)
+            assert np.array_equal(out.reshape(-1)[::max(1, out.size // 64)][:64], g[name + "_sample"][i])
