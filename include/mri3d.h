@@ -190,6 +190,18 @@ int mri3d_order_stats_f32(const float* x, int64_t n, const int64_t* ranks, int32
                           size_t ws_bytes, mri3d_stream_t stream);
 int mri3d_piecewise_linear_f32(const float* x, float* y, int64_t n, const double* edges, const double* slope,
                                const double* intercept, int32_t nseg, mri3d_stream_t stream);
+/* TorchIO transforms the notebooks apply after the histogram standardisation (segmentation/pretraining_3d_unet.ipynb cell 8:
+ * `ZNormalization(masking_method=ZNormalization.mean)`, `CropOrPad(...)`).  Third-party arithmetic, restated from its
+ * documentation ("parity unpinned"):
+ *   znorm_mean_mask: mask = x > mean(x);  y = (x - mean(x[mask])) / std(x[mask]) (unbiased);  stats (device, 4 doubles) =
+ *                    {mean of all voxels, masked count, masked mean, masked std}.
+ *   crop_or_pad:     centred crop / zero-pad of `outer` contiguous (di,hi,wi) volumes to (dout,ho,wo); the odd voxel of an
+ *                    uneven difference goes to the far end (ini = floor(diff/2)). */
+size_t mri3d_znorm_workspace_bytes(void);
+int mri3d_znorm_mean_mask_f32(const float* x, float* y, int64_t n, double* stats, void* workspace, size_t ws_bytes,
+                              mri3d_stream_t stream);
+int mri3d_crop_or_pad_f32(const float* x, float* y, int32_t outer, int32_t di, int32_t hi, int32_t wi, int32_t dout,
+                          int32_t ho, int32_t wo, float fill, mri3d_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Channel-slice plumbing: torch.cat along channels (unet.UNet decoder, modified_3dunet.py:158-178) and

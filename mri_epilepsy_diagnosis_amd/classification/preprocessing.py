@@ -115,3 +115,34 @@ def default_collate(batch, landmarks, device="cuda"):
     y = torch.as_tensor([item[1] for item in batch], dtype=torch.long)
     domain = torch.as_tensor([item[2] for item in batch], dtype=torch.long)
     return X, y, domain
+
+
+def z_normalize(tensor):
+    """TorchIO ZNormalization(masking_method=mean): (x - mean(x[x > mean(x)])) / std(x[x > mean(x)]) (unbiased std), whole
+    tensor at once, on the device.  Returns (normalised tensor, stats) with stats = float64 tensor
+    [mean of all voxels, masked count, masked mean, masked std]."""
+    if not tensor.is_cuda or tensor.dtype != torch.float32:
+        raise RuntimeError("z_normalize: needs a float32 ROCm device tensor (got %s on %s); there is no CPU fallback"
+                           % (tensor.dtype, tensor.device))
+    L = _lib.lib()
+    x = tensor.contiguous()
+    y = torch.empty_like(x)
+    stats = torch.empty(4, dtype=torch.float64, device=x.device)
+    ws = _workspace(L.mri3d_znorm_workspace_bytes(), x.device)
+    _lib.check(L.mri3d_znorm_mean_mask_f32(_ptr(x), _ptr(y), x.numel(), _ptr(stats), _ptr(ws), ws.numel(), _stream()), "znorm")
+    return y, stats
+
+
+def crop_or_pad(tensor, target_shape, fill=0.0):
+    """TorchIO CropOrPad(target_shape): centred crop / zero-pad of the last three axes of a (..., D, H, W) device tensor."""
+    if not tensor.is_cuda or tensor.dtype != torch.float32:
+        raise RuntimeError("crop_or_pad: needs a float32 ROCm device tensor (got %s on %s); there is no CPU fallback"
+                           % (tensor.dtype, tensor.device))
+    L = _lib.lib()
+    x = tensor.contiguous()
+    d, h, w = (int(v) for v in x.shape[-3:])
+    td, th, tw = (int(v) for v in target_shape)
+    outer = x.numel() // (d * h * w)
+    y = torch.empty(tuple(x.shape[:-3]) + (td, th, tw), dtype=x.dtype, device=x.device)
+    _lib.check(L.mri3d_crop_or_pad_f32(_ptr(x), _ptr(y), outer, d, h, w, td, th, tw, float(fill), _stream()), "crop_or_pad")
+    return y

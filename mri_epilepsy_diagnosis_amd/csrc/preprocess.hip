@@ -175,9 +175,123 @@ pwl_kernel(const float* __restrict__ x, float* __restrict__ y, long long n, PwlM
     }
 }
 
+// ------------------------------------------------------------------ z-normalisation over a foreground mask
+// TorchIO's ZNormalization(masking_method=mean) as the notebooks configure it (segmentation/pretraining_3d_unet.ipynb cell
+// 8, `ZNormalization(masking_method=ZNormalization.mean)`): mask = x > mean(x); y = (x - mean(x[mask])) / std(x[mask]) with
+// the unbiased (N-1) standard deviation.  Third-party arithmetic (TorchIO, version not pinned by the reference): restated
+// from its documentation — "parity unpinned".  Two reduction passes in double with fixed-order block partials.
+constexpr int kZBlocks = 512;
+
+// pass 0: part[b] = (sum, 0, count=all);  pass 1: over x > thr: part[b] = (sum (x - shift), sum (x - shift)^2, count)
+__global__ void __launch_bounds__(256)
+znorm_partial_kernel(const float* __restrict__ x, long long n, int masked, const double* __restrict__ stats,
+                     double* __restrict__ part) {
+    __shared__ double red[4][3];
+    // the threshold is compared in float32 like `tensor > tensor.mean()`; the shift only conditions the sums
+    const float thr = masked ? (float)stats[0] : 0.f;
+    const double shift = masked ? stats[0] : 0.0;
+    double s = 0.0, ss = 0.0, c = 0.0;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const float v = x[i];
+        if (!masked || v > thr) {
+            const double d = (double)v - shift;
+            s += d;
+            ss = fma(d, d, ss);
+            c += 1.0;
+        }
+    }
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    s = wave_sum_d(s);
+    ss = wave_sum_d(ss);
+    c = wave_sum_d(c);
+    if (lane == 0) { red[wave][0] = s; red[wave][1] = ss; red[wave][2] = c; }
+    __syncthreads();
+    if (threadIdx.x < 3)
+        part[(size_t)blockIdx.x * 3 + threadIdx.x] = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+}
+
+// stats[0] = mean of all voxels; stats[1] = masked count; stats[2] = masked mean; stats[3] = masked unbiased std
+__global__ void znorm_finalize_kernel(const double* __restrict__ part, int nblk, int masked, double* __restrict__ stats) {
+    if (threadIdx.x != 0) return;
+    double s = 0.0, ss = 0.0, c = 0.0;
+    for (int b = 0; b < nblk; ++b) { s += part[b * 3]; ss += part[b * 3 + 1]; c += part[b * 3 + 2]; }
+    if (!masked) {
+        stats[0] = (double)(float)(s / c);   // tensor.mean() is a float32 tensor: the mask threshold is its float32 value
+        return;
+    }
+    const double shift = stats[0];
+    const double m = c > 0.0 ? s / c : 0.0;
+    const double var = c > 1.0 ? (ss - s * m) / (c - 1.0) : 0.0;
+    stats[1] = c;
+    stats[2] = shift + m;
+    stats[3] = sqrt(var > 0.0 ? var : 0.0);
+}
+
+// y = (x - mean) / std in float32, subtraction and division rounded separately like `(tensor - mean) / std`
+__global__ void __launch_bounds__(256)
+znorm_apply_kernel(const float* __restrict__ x, float* __restrict__ y, long long n, const double* __restrict__ stats) {
+    const float mean = (float)stats[2], sd = (float)stats[3];
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+        y[i] = __fdiv_rn(__fsub_rn(x[i], mean), sd);
+}
+
+// ------------------------------------------------------------------ centred crop-or-pad
+// TorchIO's CropOrPad(target_shape) (segmentation/pretraining_3d_unet.ipynb cell 8): per axis the difference is split
+// floor/ceil between the two ends (crop: ini = floor(diff/2); pad: ini = floor(diff/2) of zeros in front).  One gather per
+// output voxel; `outer` leading (batch x channel) volumes.  Third-party semantics — "parity unpinned".
+__global__ void __launch_bounds__(256)
+crop_or_pad_kernel(const float* __restrict__ x, float* __restrict__ y, int outer, int di, int hi, int wi, int dout, int ho,
+                   int wo, int od, int oh, int ow, float fill) {
+    // (od, oh, ow) = offset of the output origin in input coordinates (negative = padding in front)
+    const long long per = (long long)dout * ho * wo, total = per * outer;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int o = (int)(i / per);
+        unsigned r = (unsigned)(i - (long long)o * per);
+        const int w = r % wo;
+        r /= wo;
+        const int h = r % ho, d = r / ho;
+        const int id = d + od, ih = h + oh, iw = w + ow;
+        const bool in = (unsigned)id < (unsigned)di && (unsigned)ih < (unsigned)hi && (unsigned)iw < (unsigned)wi;
+        y[i] = in ? x[(((long long)o * di + id) * hi + ih) * wi + iw] : fill;
+    }
+}
+
 }  // namespace mri3d
 
 using namespace mri3d;
+
+extern "C" size_t mri3d_znorm_workspace_bytes(void) { return (size_t)kZBlocks * 3 * sizeof(double); }
+
+extern "C" int mri3d_znorm_mean_mask_f32(const float* x, float* y, int64_t n, double* stats, void* workspace,
+                                         size_t ws_bytes, mri3d_stream_t stream) {
+    MRI3D_REQUIRE(x && y && stats && n > 0, MRI3D_EINVAL, "znorm: bad arguments");
+    MRI3D_REQUIRE(workspace && ws_bytes >= mri3d_znorm_workspace_bytes() && (reinterpret_cast<uintptr_t>(workspace) & 7) == 0,
+                  MRI3D_EWORKSPACE, "znorm: workspace %zu < %zu", ws_bytes, mri3d_znorm_workspace_bytes());
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    double* part = static_cast<double*>(workspace);
+    int nblk = (int)std::min<int64_t>(kZBlocks, cdiv64(n, 256 * 8));
+    if (nblk < 1) nblk = 1;
+    for (int masked = 0; masked < 2; ++masked) {
+        hipLaunchKernelGGL(znorm_partial_kernel, dim3(nblk), dim3(256), 0, s, x, (long long)n, masked, stats, part);
+        hipLaunchKernelGGL(znorm_finalize_kernel, dim3(1), dim3(64), 0, s, part, nblk, masked, stats);
+    }
+    hipLaunchKernelGGL(znorm_apply_kernel, dim3(stream_grid(n, 256 * 4)), dim3(256), 0, s, x, y, (long long)n, stats);
+    return check_launch("znorm");
+}
+
+extern "C" int mri3d_crop_or_pad_f32(const float* x, float* y, int32_t outer, int32_t di, int32_t hi, int32_t wi,
+                                     int32_t dout, int32_t ho, int32_t wo, float fill, mri3d_stream_t stream) {
+    MRI3D_REQUIRE(x && y && outer > 0 && di > 0 && hi > 0 && wi > 0 && dout > 0 && ho > 0 && wo > 0, MRI3D_EINVAL,
+                  "crop_or_pad: bad arguments");
+    MRI3D_REQUIRE((int64_t)dout * ho * wo < 0x7fffffffLL, MRI3D_ENOTSUP, "crop_or_pad: output volume too large");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    // offset of the output origin in input coordinates: crop -> +floor(diff/2); pad -> -floor(diff/2)
+    auto off = [](int in, int out) { return in >= out ? (in - out) / 2 : -((out - in) / 2); };
+    const int64_t total = (int64_t)outer * dout * ho * wo;
+    hipLaunchKernelGGL(crop_or_pad_kernel, dim3(stream_grid(total, 256 * 4)), dim3(256), 0, s, x, y, outer, di, hi, wi, dout,
+                       ho, wo, off(di, dout), off(hi, ho), off(wi, wo), fill);
+    return check_launch("crop_or_pad");
+}
 
 extern "C" size_t mri3d_order_stats_workspace_bytes(void) {
     return (size_t)(kB0 + kMaxRanks * kB1 + kMaxRanks * kB2 + kMaxRanks) * sizeof(unsigned) +

@@ -54,3 +54,28 @@ def synthetic_t1(seed, shape):
     rng = np.random.Generator(np.random.PCG64(seed))
     tissue = np.abs(rng.normal(600.0, 250.0, size=shape)) + 50.0 * rng.random(shape) ** 4
     return np.where(rng.random(shape) < 0.45, 0.0, tissue).astype(np.float32)
+
+
+def z_normalize(array):
+    """TorchIO ZNormalization(masking_method=mean) restated with torch CPU ops (third-party, "parity unpinned")."""
+    import torch
+    t = torch.as_tensor(np.asarray(array, dtype=np.float32))
+    mask = t > t.mean()
+    values = t[mask]
+    return ((t - values.mean()) / values.std()).numpy()
+
+
+def crop_or_pad(array, target_shape, fill=0.0):
+    """TorchIO CropOrPad restated: per axis, ini = floor(|diff| / 2) cropped or padded in front, the rest at the end."""
+    a = np.asarray(array)
+    for ax, tgt in zip((-3, -2, -1), target_shape):
+        n = a.shape[ax]
+        if n > tgt:
+            ini = (n - tgt) // 2
+            a = np.take(a, np.arange(ini, ini + tgt), axis=ax)
+        elif n < tgt:
+            ini = (tgt - n) // 2
+            pad = [(0, 0)] * a.ndim
+            pad[ax] = (ini, tgt - n - ini)
+            a = np.pad(a, pad, constant_values=fill)
+    return np.ascontiguousarray(a)

@@ -86,3 +86,28 @@ def test_no_cpu_fallback():
         P.normalize(torch.zeros(2, 2, 2), np.arange(13.0))
     with pytest.raises(RuntimeError):
         P.order_statistics(torch.zeros(4), [0])
+
+
+def test_z_normalize_matches_torch_restatement():
+    """ZNormalization(masking_method=mean) — third-party (TorchIO) arithmetic, "parity unpinned": checked against the
+    torch-CPU restatement to fp32 rounding of the two statistics (1e-6 relative) and through its defining properties."""
+    for seed, shape in ((1, (1, 24, 20, 28)), (2, (160, 192, 160))):
+        vol = O_PRE.synthetic_t1(seed, shape)
+        y, stats = P.z_normalize(torch.from_numpy(vol).cuda())
+        ref = O_PRE.z_normalize(vol)
+        yc = y.cpu().numpy()
+        assert np.abs(yc - ref).max() <= 2e-6 * np.abs(ref).max()
+        m = vol > np.float32(vol.astype(np.float64).mean())
+        st = stats.cpu().numpy()
+        assert st[1] == m.sum()
+        assert abs(yc[m].astype(np.float64).mean()) < 1e-5 and abs(yc[m].astype(np.float64).std(ddof=1) - 1.0) < 1e-5
+
+
+@pytest.mark.parametrize("src,tgt", [((20, 24, 18), (16, 30, 18)), ((7, 9, 11), (12, 4, 11)), ((160, 192, 160), (176, 208, 160)),
+                                     ((13, 13, 13), (6, 21, 14))])
+def test_crop_or_pad_exact(src, tgt):
+    rng = np.random.Generator(np.random.PCG64(4))
+    x = rng.normal(size=(2, 1) + src).astype(np.float32)
+    y = P.crop_or_pad(torch.from_numpy(x).cuda(), tgt)
+    assert tuple(y.shape) == (2, 1) + tgt
+    assert np.array_equal(y.cpu().numpy(), O_PRE.crop_or_pad(x, tgt))
