@@ -190,7 +190,7 @@ int mri3d_order_stats_f32(const float* x, int64_t n, const int64_t* ranks, int32
                           size_t ws_bytes, mri3d_stream_t stream);
 int mri3d_piecewise_linear_f32(const float* x, float* y, int64_t n, const double* edges, const double* slope,
                                const double* intercept, int32_t nseg, mri3d_stream_t stream);
-/* TorchIO transforms the notebooks apply after the histogram standardisation (segmentation/pretraining_3d_unet.ipynb cell 8:
+/* TorchIO transforms the notebooks apply after the histogram standardisation (segmentation/pretraining_3d_unet.ipynb cell 9:
  * `ZNormalization(masking_method=ZNormalization.mean)`, `CropOrPad(...)`).  Third-party arithmetic, restated from its
  * documentation ("parity unpinned"):
  *   znorm_mean_mask: mask = x > mean(x);  y = (x - mean(x[mask])) / std(x[mask]) (unbiased);  stats (device, 4 doubles) =

@@ -236,7 +236,7 @@ znorm_apply_kernel(const float* __restrict__ x, float* __restrict__ y, long long
 }
 
 // ------------------------------------------------------------------ centred crop-or-pad
-// TorchIO's CropOrPad(target_shape) (segmentation/pretraining_3d_unet.ipynb cell 8): per axis the difference is split
+// TorchIO's CropOrPad(target_shape) (segmentation/pretraining_3d_unet.ipynb cell 9): per axis the difference is split
 // floor/ceil between the two ends (crop: ini = floor(diff/2); pad: ini = floor(diff/2) of zeros in front).  One gather per
 // output voxel; `outer` leading (batch x channel) volumes.  Third-party semantics — "parity unpinned".
 __global__ void __launch_bounds__(256)
