@@ -203,6 +203,16 @@ int mri3d_znorm_mean_mask_f32(const float* x, float* y, int64_t n, double* stats
 int mri3d_crop_or_pad_f32(const float* x, float* y, int32_t outer, int32_t di, int32_t hi, int32_t wi, int32_t dout,
                           int32_t ho, int32_t wo, float fill, mri3d_stream_t stream);
 
+/* Average surface distance inputs of validate_dsc_asd (segmentation/routine.py:205-214): for two (d,h,w) uint8 masks
+ * (non-zero = inside) and the 256-entry surface-element area table of metrics.py:57-71 (HOST array, for the spacing in use)
+ *   sums[0] = sum(dist_to_pred_surface * area), sums[1] = sum(area) over the surface elements of gt,
+ *   sums[2], sums[3] = the same over the surface elements of pred with distances to the gt surface       (device doubles)
+ * with surface elements and areas as compute_surface_distances defines them (segmentation/metrics.py:25-178) and the exact
+ * Euclidean distance transform for unit spacing.  compute_average_surface_distance = (sums[0]/sums[1], sums[2]/sums[3]). */
+size_t mri3d_surface_distance_workspace_bytes(int32_t d, int32_t h, int32_t w);
+int mri3d_surface_distance(const uint8_t* gt, const uint8_t* pred, int32_t d, int32_t h, int32_t w,
+                           const double* area_table, double* sums, void* workspace, size_t ws_bytes, mri3d_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Channel-slice plumbing: torch.cat along channels (unet.UNet decoder, modified_3dunet.py:158-178) and
  * residual adds (modified_3dunet.py:108, cnn_model.py:34).

@@ -24,6 +24,7 @@ import numpy as np
 import torch
 
 from .. import ops
+from . import surface
 from ..unet import UNet
 
 device = torch.device("cuda") if torch.cuda.is_available() else "cpu"
@@ -84,6 +85,8 @@ def calculate_metrics(surface, prediction, surface_metrics=None):
 
 
 def validate_dsc_asd(model, loader, surface_metrics=None):
+    """Reference validate_dsc_asd (routine.py:217-237): per sample (dsc, asd gt->pred, asd pred->gt, iou).
+    surface_metrics: None = on the device (default); False = skip (NaN); a callable(surface, prediction) -> (a, b) = host."""
     dsc, asd_mean, asd_std, iou = [], [], [], []
     model.eval()
     for batch in loader:
@@ -91,11 +94,15 @@ def validate_dsc_asd(model, loader, surface_metrics=None):
         with torch.no_grad():
             logits = forward(model, inputs)
         labels = ops.argmax_mask(logits)  # (N, D, H, W) uint8 on device: no logits D2H
-        if surface_metrics is None and targets.is_cuda:
-            # Dice / IoU from exact integer overlap counts taken on the device: 40 bytes cross PCIe instead of two volumes
+        if (surface_metrics is None or surface_metrics is False) and targets.is_cuda:
+            # Dice / IoU from exact integer overlap counts and the two average surface distances from the on-device exact
+            # distance transform: a few dozen bytes cross PCIe instead of two volumes (and no 5-7 s scipy EDT per volume)
             gt = targets[0][0].to(torch.uint8)      # .astype(np.uint8) of the reference
             d, i = ops.dice_iou_from_counts(ops.mask_overlap_counts(labels[0], gt))
-            am = asd = float("nan")
+            if surface_metrics is False:
+                am = asd = float("nan")
+            else:
+                am, asd = surface.average_surface_distance(gt, labels[0])
         else:
             prediction = labels[0].cpu().numpy()
             d, am, asd, i = calculate_metrics(targets.cpu().numpy().astype(np.uint8)[0][0], prediction, surface_metrics)

@@ -307,8 +307,55 @@ def hist_std():
     print("hist_std ok", rec["mono_sum"], rec["shipped_sum"])
 
 
+def surface_asd():
+    """Product data + golden for the average surface distance (segmentation/metrics.py:25-207):
+      * mri_epilepsy_diagnosis_amd/segmentation/data/surfel_area_spacing111.npy — the 256 surface-element areas for unit
+        spacing, computed from the reference's lookup table with the reference's formula (metrics.py:57-71);
+      * tests/golden/surface_asd.npz — compute_average_surface_distance(compute_surface_distances(...)) of the REFERENCE on
+        seeded blobs and on the offset cubes of SURVEY Appendix D (known answer 0.671674); the oracle must agree to 1e-12."""
+    import importlib.util
+    import warnings
+    from oracle import metrics as O_MET
+    spec = importlib.util.spec_from_file_location("ref_metrics", os.path.join(REF, "segmentation", "metrics.py"))
+    R_MET = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(R_MET)
+    area = np.zeros(256)
+    for code in range(256):
+        normals = np.array(R_MET.neighbour_code_to_normals[code])
+        sum_area = 0
+        for normal_idx in range(normals.shape[0]):
+            n = np.zeros([3])
+            n[0] = normals[normal_idx, 0] * 1 * 1
+            n[1] = normals[normal_idx, 1] * 1 * 1
+            n[2] = normals[normal_idx, 2] * 1 * 1
+            sum_area += np.linalg.norm(n)
+        area[code] = sum_area
+    pkg = os.path.join(os.path.dirname(OUT), "..", "mri_epilepsy_diagnosis_amd", "segmentation", "data")
+    os.makedirs(pkg, exist_ok=True)
+    np.save(os.path.join(pkg, "surfel_area_spacing111.npy"), area)
+    cases = [(31, (24, 28, 20)), (32, (40, 48, 40)), (33, (33, 17, 29)), (34, (64, 72, 56))]
+    ref_vals = []
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        for seed, shape in cases:
+            gt, pred = O_MET.seeded_blobs(seed, shape)
+            r = R_MET.compute_average_surface_distance(R_MET.compute_surface_distances(gt.astype(bool), pred.astype(bool), (1, 1, 1)))
+            o = O_MET.average_surface_distance(gt, pred, area)
+            assert np.allclose(r, o, rtol=1e-12, atol=0), (r, o)
+            ref_vals.append(r)
+        a = np.zeros((32, 32, 32), np.uint8); a[4:20, 4:20, 4:20] = 1
+        b = np.zeros((32, 32, 32), np.uint8); b[6:22, 4:20, 4:20] = 1
+        cube = R_MET.compute_average_surface_distance(R_MET.compute_surface_distances(a.astype(bool), b.astype(bool), (1, 1, 1)))
+        assert abs(cube[0] - 0.671674) < 1e-6 and np.allclose(cube, O_MET.average_surface_distance(a, b, area), rtol=1e-12)
+    np.savez(os.path.join(OUT, "surface_asd.npz"), cases=np.array([(c[0],) + c[1] for c in cases]), asd=np.array(ref_vals),
+             cube_asd=np.array(cube), area_table=area)
+    print("surface asd ok", ref_vals, cube)
+
+
 if __name__ == "__main__":
-    if len(sys.argv) > 1 and sys.argv[1] == "mask_metrics":
+    if len(sys.argv) > 1 and sys.argv[1] == "surface_asd":
+        surface_asd()
+    elif len(sys.argv) > 1 and sys.argv[1] == "mask_metrics":
         mask_metrics()
     elif len(sys.argv) > 1 and sys.argv[1] == "hist_std":
         hist_std()
@@ -316,3 +363,4 @@ if __name__ == "__main__":
         main()
         mask_metrics()
         hist_std()
+        surface_asd()

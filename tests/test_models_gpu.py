@@ -383,7 +383,7 @@ def test_validate_dsc_asd_device_counts_equal_host_metrics():
     net.to(DEV)
     loader = routine.synthetic_loader(3, 1, (32, 48, 32), seed=5, foreground=0.3)
     dsc, asd_mean, asd_std, iou = routine.validate_dsc_asd(net, loader)
-    assert len(dsc) == 3 and all(np.isnan(a) for a in asd_mean)
+    assert len(dsc) == 3
     net.eval()
     for k, batch in enumerate(routine.synthetic_loader(3, 1, (32, 48, 32), seed=5, foreground=0.3)):
         with torch.no_grad():
@@ -391,6 +391,9 @@ def test_validate_dsc_asd_device_counts_equal_host_metrics():
         gt = batch[routine.LABEL][routine.DATA].numpy().astype(np.uint8)[0][0]
         assert dsc[k] == O_MET.dice_coefficient(gt, pred)
         assert iou[k] == O_MET.iou_score(pred, gt)
+        ref_a, ref_b = O_MET.average_surface_distance(gt, pred, load_golden("surface_asd.npz")["area_table"])
+        assert np.isclose(asd_mean[k], ref_a, rtol=1e-12, atol=0, equal_nan=True)
+        assert np.isclose(asd_std[k], ref_b, rtol=1e-12, atol=0, equal_nan=True)
     # the host path (surface metrics requested) gives the same Dice / IoU
     d2, _, _, i2 = routine.validate_dsc_asd(net, routine.synthetic_loader(3, 1, (32, 48, 32), seed=5, foreground=0.3),
                                             surface_metrics=lambda s, p: (0.0, 0.0))

@@ -383,3 +383,35 @@ def test_mask_overlap_counts_dice_iou_exact():
     assert dsc == O_MET.dice_coefficient(gt, pred) and iou == O_MET.iou_score(pred, gt)
     z = torch.zeros(4, 4, 4, dtype=torch.uint8, device="cuda")
     assert ops.mask_overlap_counts(z, z).tolist() == [0, 0, 0, 0, 0]    # both empty: Dice is NaN in the reference
+
+
+def test_surface_distance_device_vs_oracle_and_reference_golden():
+    """§8(f4): average surface distances from the on-device neighbour codes + exact Euclidean distance transform against the
+    oracle (scipy) and, through tests/golden/surface_asd.npz, the reference's own compute_average_surface_distance.  The
+    squared distances are exact integers; only the order of the two float64 sums differs (1e-12 relative)."""
+    import numpy as np
+    from mri_epilepsy_diagnosis_amd.segmentation import surface
+    from oracle import metrics as O_MET
+    from util import load_golden
+    g = load_golden("surface_asd.npz")
+    area = g["area_table"]
+    for row, ref in zip(g["cases"], g["asd"]):
+        gt, pred = O_MET.seeded_blobs(int(row[0]), tuple(int(v) for v in row[1:]))
+        got = surface.average_surface_distance(torch.from_numpy(gt).cuda(), torch.from_numpy(pred).cuda())
+        assert np.allclose(got, ref, rtol=1e-12, atol=0), (got, ref)
+    a = np.zeros((32, 32, 32), np.uint8); a[4:20, 4:20, 4:20] = 1
+    b = np.zeros((32, 32, 32), np.uint8); b[6:22, 4:20, 4:20] = 1
+    got = surface.average_surface_distance(torch.from_numpy(a).cuda(), torch.from_numpy(b).cuda())
+    assert np.allclose(got, g["cube_asd"], rtol=1e-12) and abs(got[0] - 0.671674) < 1e-6
+    # edge cases of the reference: one mask empty -> inf / nan, both empty -> nan, nan; mask touching the volume border
+    z = np.zeros((8, 9, 10), np.uint8)
+    full = np.ones((8, 9, 10), np.uint8)
+    for gt, pred in ((a[:8, :9, :10], z), (z, z), (full, a[:8, :9, :10] | 1), (full, z)):
+        got = surface.average_surface_distance(torch.from_numpy(np.ascontiguousarray(gt)).cuda(),
+                                               torch.from_numpy(np.ascontiguousarray(pred)).cuda())
+        ref = O_MET.average_surface_distance(gt, pred, area)
+        assert np.allclose(got, ref, rtol=1e-12, atol=0, equal_nan=True), (got, ref)
+    # full-size volume
+    gt, pred = O_MET.seeded_blobs(5, (160, 192, 160))
+    got = surface.average_surface_distance(torch.from_numpy(gt).cuda(), torch.from_numpy(pred).cuda())
+    assert np.allclose(got, O_MET.average_surface_distance(gt, pred, area), rtol=1e-12, atol=0)

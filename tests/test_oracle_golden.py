@@ -198,3 +198,22 @@ def test_hist_std_oracle_matches_reference_golden():
             assert out.dtype == np.float32
             assert hashlib.sha256(out.tobytes()).hexdigest() == str(g[name + "_sha256"][i]), (name, i)
             assert np.array_equal(out.reshape(-1)[::max(1, out.size // 64)][:64], g[name + "_sample"][i])
+
+
+def test_surface_asd_oracle_matches_reference_golden():
+    """oracle.metrics.average_surface_distance against compute_average_surface_distance(compute_surface_distances(...)) of
+    the reference recorded in tests/golden/surface_asd.npz (oracle/gen_golden.py surface_asd), and the shipped area table."""
+    import os
+    import numpy as np
+    from oracle import metrics as O_MET
+    from util import ROOT, load_golden
+    g = load_golden("surface_asd.npz")
+    area = np.load(os.path.join(ROOT, "mri_epilepsy_diagnosis_amd", "segmentation", "data", "surfel_area_spacing111.npy"))
+    assert np.array_equal(area, g["area_table"]) and area.shape == (256,) and area[0] == 0 and area[255] == 0
+    for row, ref in zip(g["cases"], g["asd"]):
+        gt, pred = O_MET.seeded_blobs(int(row[0]), tuple(int(v) for v in row[1:]))
+        assert np.allclose(O_MET.average_surface_distance(gt, pred, area), ref, rtol=1e-12, atol=0)
+    a = np.zeros((32, 32, 32), np.uint8); a[4:20, 4:20, 4:20] = 1
+    b = np.zeros((32, 32, 32), np.uint8); b[6:22, 4:20, 4:20] = 1
+    got = O_MET.average_surface_distance(a, b, area)
+    assert np.allclose(got, g["cube_asd"], rtol=1e-12) and abs(got[0] - 0.671674) < 1e-6     # SURVEY Appendix D
