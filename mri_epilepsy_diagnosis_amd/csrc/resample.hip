@@ -322,23 +322,29 @@ upsample_bwd_kernel(Mri3dUpGeom g, const T* __restrict__ dy, T* __restrict__ dx,
 // its 64 taps from LDS with immediate offsets.  Per-axis weights of the 4 taps o = 2i-1 .. 2i+2 are (.25,.75,.75,.25),
 // except at the borders where ATen's clamped source index folds a whole fine voxel into the edge: i = 0 -> (0,1,.75,.25),
 // i = S-1 -> (.25,.75,1,0).
-constexpr int UTD = 2, UTH = 4, UTW = 16;
-constexpr int UFD = 2 * UTD + 2, UFH = 2 * UTH + 2, UFW = 2 * UTW + 2;
-constexpr int UFV = UFD * UFH * UFW;   // 2040 fine voxels
-
 __device__ __forceinline__ void up2_axis_weights(int i, int S, float (&w)[4]) {
     w[0] = 0.25f; w[1] = 0.75f; w[2] = 0.75f; w[3] = 0.25f;
     if (i == 0) { w[0] = 0.f; w[1] = 1.f; }
     if (i == S - 1) { w[2] = 1.f; w[3] = 0.f; }
 }
 
-template <typename T>
+// CQ = channel quads per pass (2: 8 channels, 4: 16 channels).  A voxel's slice of CQ*4 channels is what one staging
+// request reads contiguously: 32 B (CQ = 2) left three quarters of every 128-byte line unused (2 TB/s of L2->LDS traffic
+// measured as the bound), so the 16-channel variant with a 2x2x16 coarse tile is used whenever C % 16 == 0.
+template <int CQ> struct Up2Tile;
+template <> struct Up2Tile<2> { static constexpr int TD = 2, TH = 4, TW = 16; };
+template <> struct Up2Tile<4> { static constexpr int TD = 2, TH = 2, TW = 16; };
+
+template <typename T, int CQ>
 __global__ void __launch_bounds__(256, 2)
 upsample2x_bwd_kernel(Mri3dUpGeom g, const T* __restrict__ dy, T* __restrict__ dx, int tilesD, int tilesH, int tilesW,
                       int ntiles) {
-    extern __shared__ __attribute__((aligned(16))) float4 ubuf[];   // [fine voxel][2 channel quads]
+    constexpr int UTD = Up2Tile<CQ>::TD, UTH = Up2Tile<CQ>::TH, UTW = Up2Tile<CQ>::TW;
+    constexpr int UFD = 2 * UTD + 2, UFH = 2 * UTH + 2, UFW = 2 * UTW + 2, UFV = UFD * UFH * UFW;
+    static_assert(UTD * UTH * UTW * CQ == 256, "one lane per (coarse voxel, channel quad)");
+    extern __shared__ __attribute__((aligned(16))) float4 ubuf[];   // [fine voxel][CQ channel quads]
     const int tid = threadIdx.x;
-    const int q = tid & 1, v = tid >> 1;
+    const int q = tid % CQ, v = tid / CQ;
     const int iwl = v % UTW, ihl = (v / UTW) % UTH, idl = v / (UTW * UTH);
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         int t = tile;
@@ -355,39 +361,42 @@ upsample2x_bwd_kernel(Mri3dUpGeom g, const T* __restrict__ dy, T* __restrict__ d
         up2_axis_weights(id, g.di, wd);
         up2_axis_weights(ih, g.hi, wh);
         up2_axis_weights(iw, g.wi, ww);
-        for (int c0 = 0; c0 < g.c; c0 += 8) {
+        for (int c0 = 0; c0 < g.c; c0 += 4 * CQ) {
             __syncthreads();
-            // all 16 pieces of a lane are fetched (clamped, unconditional) before the first LDS write: a load inside a
-            // branch serialises the loop into 16 dependent round trips (1.07 ms -> measured below for the c32 level)
-            constexpr int NP = (UFV * 2 + 255) / 256;
-            float4 pv[NP];
-            unsigned okm = 0;
+            // pieces are fetched (clamped, unconditional) in batches of 10 before their LDS writes: a load inside a branch
+            // serialises the loop into dependent round trips
+            constexpr int NP = (UFV * CQ + 255) / 256, NB = 10;
 #pragma unroll
-            for (int j = 0; j < NP; ++j) {
-                const int idx = j * 256 + tid;
-                const int qq = idx & 1, fv = idx >> 1;
-                const int fw = fv % UFW, t2 = fv / UFW;
-                const int fh = t2 % UFH, fd = t2 / UFH;
-                const int od = 2 * d0 - 1 + fd, oh = 2 * h0 - 1 + fh, ow = 2 * w0 - 1 + fw;
-                const int cc = c0 + 4 * qq;
-                const bool ok = idx < UFV * 2 && (unsigned)od < (unsigned)g.dout && (unsigned)oh < (unsigned)g.ho &&
-                                (unsigned)ow < (unsigned)g.wo && cc < g.c;
-                okm |= ok ? (1u << j) : 0u;
-                const int cd = min(max(od, 0), g.dout - 1), ch = min(max(oh, 0), g.ho - 1), cw = min(max(ow, 0), g.wo - 1);
-                pv[j] = ldf4(dn + (((int64_t)cd * g.ho + ch) * g.wo + cw) * g.y_ld + (cc < g.c ? cc : 0));
-            }
+            for (int j0 = 0; j0 < NP; j0 += NB) {
+                float4 pv[NB];
+                unsigned okm = 0;
 #pragma unroll
-            for (int j = 0; j < NP; ++j) {
-                const int idx = j * 256 + tid;
-                const bool ok = (okm >> j) & 1u;
-                float4 val;
-                val.x = ok ? pv[j].x : 0.f; val.y = ok ? pv[j].y : 0.f; val.z = ok ? pv[j].z : 0.f; val.w = ok ? pv[j].w : 0.f;
-                if (idx < UFV * 2) ubuf[idx] = val;
+                for (int jj = 0; jj < NB; ++jj) {
+                    const int idx = (j0 + jj) * 256 + tid;
+                    const int qq = idx % CQ, fv = idx / CQ;
+                    const int fw = fv % UFW, t2 = fv / UFW;
+                    const int fh = t2 % UFH, fd = t2 / UFH;
+                    const int od = 2 * d0 - 1 + fd, oh = 2 * h0 - 1 + fh, ow = 2 * w0 - 1 + fw;
+                    const int cc = c0 + 4 * qq;
+                    const bool ok = j0 + jj < NP && idx < UFV * CQ && (unsigned)od < (unsigned)g.dout &&
+                                    (unsigned)oh < (unsigned)g.ho && (unsigned)ow < (unsigned)g.wo && cc < g.c;
+                    okm |= ok ? (1u << jj) : 0u;
+                    const int cd = min(max(od, 0), g.dout - 1), ch = min(max(oh, 0), g.ho - 1), cw = min(max(ow, 0), g.wo - 1);
+                    pv[jj] = ldf4(dn + (((int64_t)cd * g.ho + ch) * g.wo + cw) * g.y_ld + (cc < g.c ? cc : 0));
+                }
+#pragma unroll
+                for (int jj = 0; jj < NB; ++jj) {
+                    const int idx = (j0 + jj) * 256 + tid;
+                    const bool ok = (okm >> jj) & 1u;
+                    float4 val;
+                    val.x = ok ? pv[jj].x : 0.f; val.y = ok ? pv[jj].y : 0.f; val.z = ok ? pv[jj].z : 0.f; val.w = ok ? pv[jj].w : 0.f;
+                    if (j0 + jj < NP && idx < UFV * CQ) ubuf[idx] = val;
+                }
             }
             __syncthreads();
             if (vok && c0 + 4 * q < g.c) {
                 float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-                const float4* base = ubuf + (((2 * idl) * UFH + 2 * ihl) * UFW + 2 * iwl) * 2 + q;
+                const float4* base = ubuf + (((2 * idl) * UFH + 2 * ihl) * UFW + 2 * iwl) * CQ + q;
 #pragma unroll
                 for (int a = 0; a < 4; ++a)
 #pragma unroll
@@ -396,7 +405,7 @@ upsample2x_bwd_kernel(Mri3dUpGeom g, const T* __restrict__ dy, T* __restrict__ d
 #pragma unroll
                         for (int c = 0; c < 4; ++c) {
                             const float w = wab * ww[c];
-                            const float4 gv = base[((a * UFH + b) * UFW + c) * 2];
+                            const float4 gv = base[((a * UFH + b) * UFW + c) * CQ];
                             acc.x = fmaf(w, gv.x, acc.x);
                             acc.y = fmaf(w, gv.y, acc.y);
                             acc.z = fmaf(w, gv.z, acc.z);
@@ -405,6 +414,79 @@ upsample2x_bwd_kernel(Mri3dUpGeom g, const T* __restrict__ dy, T* __restrict__ d
                     }
                 stf4(dx + ((((int64_t)n * g.di + id) * g.hi + ih) * g.wi + iw) * g.x_ld + c0 + 4 * q, acc);
             }
+        }
+    }
+}
+
+// ------------------------------------------------------------------ trilinear x2 forward, LDS-tiled
+// One lane = one coarse voxel x one channel quad: it reads its 3x3x3 coarse neighbourhood from an LDS halo tile and writes
+// the 2x2x2 fine voxels it owns (fine index 2i+e takes 0.75 of coarse i and 0.25 of coarse i-1 (e = 0) or i+1 (e = 1);
+// at the volume borders ATen's clamped source index gives the edge voxel weight 1).  The generic gather above recomputes
+// source indices and weights per fine element and reads 8 coarse voxels per 16-byte result from L2 (2.0 TB/s measured).
+constexpr int FTD = 1, FTH = 4, FTWD = 8;                 // coarse tile; 32 voxels x 8 channel quads = 256 lanes
+constexpr int FHD = FTD + 2, FHH = FTH + 2, FHW = FTWD + 2, FHV = FHD * FHH * FHW;   // 180 halo voxels
+
+template <typename T>
+__global__ void __launch_bounds__(256)
+upsample2x_fwd_kernel(Mri3dUpGeom g, const T* __restrict__ x, T* __restrict__ y, int tilesD, int tilesH, int tilesW,
+                      int ntiles, int cpasses) {
+    __shared__ float4 cbuf[FHV * 8];   // [halo voxel][8 channel quads] = 23 KB
+    const int tid = threadIdx.x;
+    const int q = tid & 7, v = tid >> 3;
+    const int iwl = v % FTWD, ihl = (v / FTWD) % FTH;
+    for (int item = blockIdx.x; item < ntiles * cpasses; item += gridDim.x) {
+        int t = item / cpasses;
+        const int c0 = (item % cpasses) * 32;
+        const int w0 = (t % tilesW) * FTWD;
+        t /= tilesW;
+        const int h0 = (t % tilesH) * FTH;
+        t /= tilesH;
+        const int d0 = (t % tilesD) * FTD;
+        const int n = t / tilesD;
+        const T* xn = x + (int64_t)n * g.di * g.hi * g.wi * g.x_ld;
+        __syncthreads();
+        for (int idx = tid; idx < FHV * 8; idx += 256) {   // clamped coarse halo (clamping IS the border rule)
+            const int qq = idx & 7, hv = idx >> 3;
+            const int fw = hv % FHW, t2 = hv / FHW;
+            const int fh = t2 % FHH, fd = t2 / FHH;
+            const int cd = min(max(d0 - 1 + fd, 0), g.di - 1), ch = min(max(h0 - 1 + fh, 0), g.hi - 1),
+                      cw = min(max(w0 - 1 + fw, 0), g.wi - 1);
+            const int cc = c0 + 4 * qq;
+            cbuf[idx] = cc < g.c ? ldf4(xn + (((int64_t)cd * g.hi + ch) * g.wi + cw) * g.x_ld + cc) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        __syncthreads();
+        const int id = d0, ih = h0 + ihl, iw = w0 + iwl;
+        if (ih < g.hi && iw < g.wi && c0 + 4 * q < g.c) {
+            const float4* base = cbuf + ((1 * FHH + (ihl + 1)) * FHW + (iwl + 1)) * 8 + q;   // the lane's own coarse voxel
+#pragma unroll
+            for (int ed = 0; ed < 2; ++ed)
+#pragma unroll
+                for (int eh = 0; eh < 2; ++eh)
+#pragma unroll
+                    for (int ew = 0; ew < 2; ++ew) {
+                        // the second source voxel per axis lies at -1 for the even fine index and +1 for the odd one; the clamped
+                        // halo makes the border case (all weight on the edge voxel) fall out of 0.75*a + 0.25*a
+                        float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+                        for (int a = 0; a < 2; ++a)
+#pragma unroll
+                            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                                for (int c = 0; c < 2; ++c) {
+                                    // torch order: (d0,h0,w0),(d0,h0,w1),... with index0 = the LOWER source index
+                                    const int dd = ed ? a : a - 1, hh = eh ? b : b - 1, wwi = ew ? c : c - 1;   // offsets -1..1
+                                    const float wd = (dd == 0) ? 0.75f : 0.25f, wh = (hh == 0) ? 0.75f : 0.25f,
+                                                wq = (wwi == 0) ? 0.75f : 0.25f;
+                                    const float wgt = wd * wh * wq;
+                                    const float4 cv = base[((dd * FHH + hh) * FHW + wwi) * 8];
+                                    o.x = fmaf(wgt, cv.x, o.x);
+                                    o.y = fmaf(wgt, cv.y, o.y);
+                                    o.z = fmaf(wgt, cv.z, o.z);
+                                    o.w = fmaf(wgt, cv.w, o.w);
+                                }
+                        const int od = 2 * id + ed, oh = 2 * ih + eh, ow = 2 * iw + ew;
+                        stf4(y + ((((int64_t)n * g.dout + od) * g.ho + oh) * g.wo + ow) * g.y_ld + c0 + 4 * q, o);
+                    }
         }
     }
 }
@@ -503,6 +585,20 @@ extern "C" int mri3d_upsample3d_fwd(const Mri3dUpGeom* g, const void* x, void* y
     if (rc) return rc;
     MRI3D_REQUIRE(x && y, MRI3D_EINVAL, "upsample3d_fwd: null pointer");
     hipStream_t s = static_cast<hipStream_t>(stream);
+    static const int no_fast_f = getenv("MRI3D_UP_GENERIC") ? atoi(getenv("MRI3D_UP_GENERIC")) : 0;   // tuning aid (A/B)
+    if (!no_fast_f && up2x_fast_ok(*g) && aligned_vec4(g->dtype, x, y)) {
+        const int tilesD = cdiv(g->di, FTD), tilesH = cdiv(g->hi, FTH), tilesW = cdiv(g->wi, FTWD);
+        const int64_t nt = (int64_t)g->n * tilesD * tilesH * tilesW;
+        const int cpasses = cdiv(g->c, 32);
+        if (nt * cpasses <= 0x7fffffff) {
+            const int grid = (int)std::min<int64_t>(nt * cpasses, 8192);
+            MRI3D_DISPATCH_DTYPE(g->dtype, T, {
+                hipLaunchKernelGGL(upsample2x_fwd_kernel<T>, dim3(grid), dim3(256), 0, s, *g, (const T*)x, (T*)y, tilesD, tilesH,
+                                   tilesW, (int)nt, cpasses);
+            });
+            return check_launch("upsample3d_fwd(2x)");
+        }
+    }
     bool v4 = vec_ok(g->dtype, g->c, g->x_ld, g->y_ld, x, y);
     int hch, grid;
     slab_plan(g->n * g->dout, g->ho, g->wo, g->c / (v4 ? 4 : 1), hch, grid);
@@ -525,18 +621,27 @@ extern "C" int mri3d_upsample3d_bwd(const Mri3dUpGeom* g, const void* dy, void* 
     hipStream_t s = static_cast<hipStream_t>(stream);
     static const int no_fast = getenv("MRI3D_UP_GENERIC") ? atoi(getenv("MRI3D_UP_GENERIC")) : 0;   // tuning aid (A/B)
     if (!no_fast && up2x_fast_ok(*g) && aligned_vec4(g->dtype, dx, dy)) {
-        const int tilesD = cdiv(g->di, UTD), tilesH = cdiv(g->hi, UTH), tilesW = cdiv(g->wi, UTW);
+        // 16-channel passes pay off for fp32 (0.93 vs 1.25 ms on the c32 level); bf16 already reads 32-byte slices with 8
+        // channels... measured 0.68 ms (CQ = 2) vs 0.96 ms (CQ = 4), so it keeps the 8-channel tile
+        const bool wide = g->c % 16 == 0 && g->dtype == MRI3D_F32;
+        const int utd = wide ? Up2Tile<4>::TD : Up2Tile<2>::TD, uth = wide ? Up2Tile<4>::TH : Up2Tile<2>::TH, utw = 16;
+        const int tilesD = cdiv(g->di, utd), tilesH = cdiv(g->hi, uth), tilesW = cdiv(g->wi, utw);
         const int64_t nt = (int64_t)g->n * tilesD * tilesH * tilesW;
         if (nt <= 0x7fffffff) {
-            const size_t smem = (size_t)UFV * 2 * sizeof(float4);
+            const size_t smem = (size_t)(2 * utd + 2) * (2 * uth + 2) * (2 * utw + 2) * (wide ? 4 : 2) * sizeof(float4);
             const int grid = (int)std::min<int64_t>(nt, 2048);
+#define MRI3D_UP2B(CQv)                                                                                               \
+    {                                                                                                                 \
+        auto kern = upsample2x_bwd_kernel<T, CQv>;                                                                    \
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,   \
+                                  (int)smem);                                                                         \
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(256), smem, s, *g, (const T*)dy, (T*)dx, tilesD, tilesH, tilesW,    \
+                           (int)nt);                                                                                  \
+    }
             MRI3D_DISPATCH_DTYPE(g->dtype, T, {
-                auto kern = upsample2x_bwd_kernel<T>;
-                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                          (int)smem);
-                hipLaunchKernelGGL(kern, dim3(grid), dim3(256), smem, s, *g, (const T*)dy, (T*)dx, tilesD, tilesH, tilesW,
-                                   (int)nt);
+                if (wide) MRI3D_UP2B(4) else MRI3D_UP2B(2)
             });
+#undef MRI3D_UP2B
             return check_launch("upsample3d_bwd(2x)");
         }
     }
