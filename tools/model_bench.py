@@ -26,7 +26,7 @@ if which == "all":
     # later steps (full-AE step 23 ms in sequence vs 10.3 ms on its own)
     import subprocess
     rc = 0
-    for cfg in ("cfg3", "cfg3ae", "cfg5", "m3d", "cfg2", "cfg4"):
+    for cfg in ("cfg3", "cfg3ae", "cfg5", "m3d", "m3d_graph", "cfg2", "cfg4"):
         rc |= subprocess.run([sys.executable, os.path.abspath(__file__), cfg]).returncode
     sys.exit(rc)
 dev = torch.device("cuda")
@@ -105,6 +105,21 @@ if which == "m3d":
         ops.softmax_dice_loss(m(x6), t6).backward()
         opt.step()
     run("Modified3DUNet(1,2,8) dice step, 1 x 160x192x160", 1, step6)
+if which == "m3d_graph":
+    # the same step with forward+backward replayed as one hipGraph (parallel.CapturedStep) and the fused flat AdamW
+    from mri_epilepsy_diagnosis_amd import parallel
+    torch.manual_seed(0)
+    m = Modified3DUNet(1, 2, 8).to(dev)
+    flat = parallel.FlatParams(m)
+    fopt = parallel.FlatAdam(flat, lr=1e-3, weight_decay=0.01, decoupled=True)
+    x6 = torch.randn(1, 1, 160, 192, 160, device=dev, generator=g)
+    t6 = (torch.rand(1, 1, 160, 192, 160, device=dev, generator=g) < 0.1).float()
+    cap = parallel.CapturedStep(flat, lambda: ops.softmax_dice_loss(m(x6), t6)).capture()
+
+    def step6g():
+        cap.run()
+        fopt.step(flat.all_reduce())
+    run("Modified3DUNet(1,2,8) dice step, hipGraph fwd+bwd, 1 x 160x192x160", 1, step6g)
 for tag, use_bf16 in (("cfg2", False), ("cfg4", True)):
     if which != tag:
         continue
