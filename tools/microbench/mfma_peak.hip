@@ -85,6 +85,27 @@ __global__ void __launch_bounds__(256) bf16_32_kernel(float* out, int iters, flo
     out[blockIdx.x * blockDim.x + threadIdx.x] = s;
 }
 
+// multi-block shapes: v_mfma_f32_16x16x1_4b_f32 (four independent 16x16 rank-1 updates, 16 accumulator registers)
+template <int NACC>
+__global__ void __launch_bounds__(256) f32_16x1_kernel(float* out, int iters, float a0, float b0) {
+    f32x16 acc[NACC];
+#pragma unroll
+    for (int i = 0; i < NACC; ++i)
+#pragma unroll
+        for (int j = 0; j < 16; ++j) acc[i][j] = 0.f;
+    float a = a0 + threadIdx.x, b = b0;
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int i = 0; i < NACC; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x1f32(a, b, acc[i], 0, 0, 0);
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NACC; ++i)
+#pragma unroll
+        for (int j = 0; j < 16; ++j) s += acc[i][j];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+
 template <typename F>
 static double time_ms(F launch) {
     hipEvent_t e0, e1;
@@ -121,6 +142,21 @@ int main() {
             double ms = time_ms([&] { hipLaunchKernelGGL(f32_32_kernel<4>, dim3(grid), dim3(256), 0, 0, out, iters, 1.0f, 2.0f); });
             double flops = (double)grid * 4 * iters * 4 * 4096.0;
             printf("fp32 32x32x2  %d waves/SIMD: %.2f ms  %.1f TFLOP/s\n", wgs_per_cu, ms, flops / ms / 1e9);
+        }
+        {
+            double ms = time_ms([&] { hipLaunchKernelGGL(f32_16x1_kernel<4>, dim3(grid), dim3(256), 0, 0, out, iters, 1.0f, 2.0f); });
+            double flops = (double)grid * 4 * iters * 4 * 2048.0;
+            printf("fp32 16x16x1_4b %d waves/SIMD: %.2f ms  %.1f TFLOP/s\n", wgs_per_cu, ms, flops / ms / 1e9);
+        }
+        {   // dependency distance: the same instruction with only 2 / 1 independent accumulators
+            double ms = time_ms([&] { hipLaunchKernelGGL(f32_16x1_kernel<2>, dim3(grid), dim3(256), 0, 0, out, iters, 1.0f, 2.0f); });
+            printf("fp32 16x16x1_4b %d waves/SIMD, 2 accumulators: %.1f TFLOP/s\n", wgs_per_cu, (double)grid * 4 * iters * 2 * 2048.0 / ms / 1e9);
+            ms = time_ms([&] { hipLaunchKernelGGL(f32_16x1_kernel<1>, dim3(grid), dim3(256), 0, 0, out, iters, 1.0f, 2.0f); });
+            printf("fp32 16x16x1_4b %d waves/SIMD, 1 accumulator:  %.1f TFLOP/s\n", wgs_per_cu, (double)grid * 4 * iters * 1 * 2048.0 / ms / 1e9);
+#define F32_SWEEP(NA)                                                                                                  \
+    ms = time_ms([&] { hipLaunchKernelGGL(f32_kernel<NA>, dim3(grid), dim3(256), 0, 0, out, iters, 1.0f, 2.0f); });              \
+    printf("fp32 16x16x4    %d waves/SIMD, %d accumulators: %.1f TFLOP/s\n", wgs_per_cu, NA, (double)grid * 4 * iters * NA * 2048.0 / ms / 1e9);
+            F32_SWEEP(1) F32_SWEEP(2) F32_SWEEP(3) F32_SWEEP(4) F32_SWEEP(5) F32_SWEEP(6) F32_SWEEP(7) F32_SWEEP(16) F32_SWEEP(28)
         }
         {
             double ms = time_ms([&] { hipLaunchKernelGGL(bf16_32_kernel<4>, dim3(grid), dim3(256), 0, 0, out, iters, 1.0f); });
