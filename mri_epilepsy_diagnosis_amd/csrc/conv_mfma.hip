@@ -1286,7 +1286,10 @@ conv_mfma_wgrad6_kernel(const float* __restrict__ x, const float* __restrict__ d
     const int s_q = tid & 3, s_wg = (tid >> 2) & 3, s_row = tid >> 4;      // unit u = tid (+256): row = s_row (+16)
     const int h_q = tid & 3, h_side = (tid >> 2) & 1, h_row = tid >> 3;
     const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
-    const int p_off = kq == 0 ? 64 : 16 * kq - 4, n_off = kq == 3 ? 68 : 16 * kq + 16;
+    const int p_off = kq == 0 ? 64 : 16 * kq - 4, n_off = kq == 3 ? 68 : 16 * kq + 16, g_off = 16 * kq;
+    const int orow0 = wv * (BYR / 4);   // first of the wave's three output rows (same d-plane, consecutive h)
+    const char* const xrow0 = xs + (((orow0 / BTH) * BHH + orow0 % BTH) * 16 + li) * BRS;   // X line of tap (kd,kh) = (0,0)
+    const char* const yrow0 = ys + (orow0 * 16 + li) * BRS + 16 * kq;
 
     // next tile's pieces: fetched into registers while the current tile is multiplied (HBM/L2 latency hidden), written to
     // the single LDS tile between two barriers after it
@@ -1363,11 +1366,13 @@ conv_mfma_wgrad6_kernel(const float* __restrict__ x, const float* __restrict__ d
         __builtin_amdgcn_sched_barrier(0);
 
         // ---- 3 output rows per wave x 9 (kd, kh) x 3 kw x 4 k-steps
+        // the wave's three rows are consecutive in h (same d): row pointers advance by a constant, every tap is an
+        // immediate offset — no per-row address arithmetic (each VALU instruction costs MFMA time)
+        const char* xrow = xrow0;
+        const char* yrow = yrow0;
 #pragma unroll 1
-        for (int r = 0; r < BYR / 4; ++r) {
-            const int orow = wv * (BYR / 4) + r;
-            const int dz = orow / BTH, hy = orow % BTH;
-            const float4 b = *reinterpret_cast<const float4*>(ys + (orow * 16 + li) * BRS + 16 * kq);
+        for (int r = 0; r < BYR / 4; ++r, xrow += 16 * BRS, yrow += 16 * BRS) {
+            const float4 b = *reinterpret_cast<const float4*>(yrow);
             const float bk[4] = {b.x, b.y, b.z, b.w};
             if (BIAS) {
 #pragma unroll
@@ -1375,11 +1380,11 @@ conv_mfma_wgrad6_kernel(const float* __restrict__ x, const float* __restrict__ d
             }
 #pragma unroll
             for (int kdh = 0; kdh < 9; ++kdh) {
-                const int xr = (dz + kdh / 3) * BHH + hy + kdh % 3;
-                const char* base = xs + (xr * 16 + li) * BRS;
-                const float4 g = *reinterpret_cast<const float4*>(base + 16 * kq);
-                const float pp = *reinterpret_cast<const float*>(base + p_off);
-                const float nn = *reinterpret_cast<const float*>(base + n_off);
+                constexpr int kOff = 0;
+                const int loff = ((kdh / 3) * BHH + kdh % 3) * 16 * BRS + kOff;   // compile-time after unrolling
+                const float4 g = *reinterpret_cast<const float4*>(xrow + g_off + loff);
+                const float pp = *reinterpret_cast<const float*>(xrow + p_off + loff);
+                const float nn = *reinterpret_cast<const float*>(xrow + n_off + loff);
                 const float a0[4] = {pp, g.x, g.y, g.z}, a1[4] = {g.x, g.y, g.z, g.w}, a2[4] = {g.y, g.z, g.w, nn};
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
@@ -1462,10 +1467,9 @@ static bool mfma_wgrad_plan(const Mri3dConvGeom& g, MfmaWgradPlan& p) {
     p.v2 = (!use_v1 && g.ci % 8 == 0 && g.co % 4 == 0 && g.y_ld % 4 == 0) ? (g.ci % 16 == 0 ? 2 : 1) : 0;
     static const int no_bf = getenv("MRI3D_WGRAD_BF16_OFF") ? atoi(getenv("MRI3D_WGRAD_BF16_OFF")) : 0;   // tuning aid (A/B)
     if (g.dtype == MRI3D_BF16 && !no_bf && g.ci % 8 == 0 && g.co % 8 == 0 && g.x_ld % 8 == 0 && g.y_ld % 8 == 0) p.v2 = 3;
-    // 4 = v6 (fp32 transposed-tile kernel).  Measured on MI355X: v6 wins where v4's interior-tile fast path covers few
-    // tiles (W = 80: 96->32 97.0 vs 89.5, 32->32 94.3 vs 89.9 TFLOP/s), v4 at W = 160 (48->16 102.7 vs 101.8).
+    // 4 = v6 (fp32 transposed-tile kernel): 110 / 104 / 102 TFLOP/s on 48->16 / 96->32 / 16->16 against v4's 103 / 90 / 99
     static const int force_v6 = getenv("MRI3D_WGRAD_V6") ? atoi(getenv("MRI3D_WGRAD_V6")) : -1;   // tuning aid (A/B): 0 / 1
-    if (p.v2 == 2 && g.dtype == MRI3D_F32 && (force_v6 < 0 ? g.wi < 128 : force_v6 != 0)) p.v2 = 4;
+    if (p.v2 == 2 && g.dtype == MRI3D_F32 && (force_v6 < 0 || force_v6 != 0)) p.v2 = 4;
     if (p.v2 == 3) p.CK = 16;
     else if (g.ci % 16 == 0) p.CK = 16;
     else if (g.ci % 8 == 0) p.CK = 8;
