@@ -1143,6 +1143,9 @@ conv_mfma_wgrad_bf16_kernel(const bf16_t* __restrict__ x, const bf16_t* __restri
     const uint4 zero4 = make_uint4(0u, 0u, 0u, 0u);
     // per-lane operand offsets
     const int p_off = kq == 0 ? 64 : 16 * kq - 4, n_off = kq == 3 ? 64 : 16 * kq + 16;
+    const int orow0 = wv * (BYR / 4);   // first of the wave's three output rows (same d-plane, consecutive h)
+    const char* const xrow0 = xs + (((orow0 / BTH) * BHH + orow0 % BTH) * 16 + li) * BRS;
+    const char* const yrow0 = ys + (orow0 * 16 + li) * BRS + 16 * kq;
     bf16x8_t ones;
 #pragma unroll
     for (int i = 0; i < 8; ++i) ones[i] = (bf16_t)1.0f;
@@ -1206,19 +1209,19 @@ conv_mfma_wgrad_bf16_kernel(const bf16_t* __restrict__ x, const bf16_t* __restri
         __syncthreads();
 
         // ---- 3 output rows per wave x 9 (kd, kh) x 3 kw MFMAs
+        // the wave's three rows are consecutive in h: constant-stride row pointers, every tap an immediate offset
+        const char* xrow = xrow0;
+        const char* yrow = yrow0;
 #pragma unroll 1
-        for (int r = 0; r < BYR / 4; ++r) {
-            const int orow = wv * (BYR / 4) + r;
-            const int dz = orow / BTH, hy = orow % BTH;
-            const bf16x8_t b = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(ys + (orow * 16 + li) * BRS + 16 * kq));
+        for (int r = 0; r < BYR / 4; ++r, xrow += 16 * BRS, yrow += 16 * BRS) {
+            const bf16x8_t b = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(yrow));
             if (BIAS) acc[TG] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, b, acc[TG], 0, 0, 0);
 #pragma unroll
             for (int kdh = 0; kdh < 9; ++kdh) {
-                const int xr = (dz + kdh / 3) * BHH + hy + kdh % 3;
-                const char* base = xs + (xr * 16 + li) * BRS;
-                const uint4 g = *reinterpret_cast<const uint4*>(base + 16 * kq);
-                const unsigned pp = *reinterpret_cast<const unsigned*>(base + p_off);
-                const unsigned nn = *reinterpret_cast<const unsigned*>(base + n_off);
+                const int loff = ((kdh / 3) * BHH + kdh % 3) * 16 * BRS;   // compile-time after unrolling
+                const uint4 g = *reinterpret_cast<const uint4*>(xrow + 16 * kq + loff);
+                const unsigned pp = *reinterpret_cast<const unsigned*>(xrow + p_off + loff);
+                const unsigned nn = *reinterpret_cast<const unsigned*>(xrow + n_off + loff);
                 uint4 a0, a2;
                 a0.x = __builtin_amdgcn_alignbyte(g.x, pp, 2);
                 a0.y = __builtin_amdgcn_alignbyte(g.y, g.x, 2);
