@@ -212,6 +212,14 @@ int mri3d_crop_or_pad_f32(const float* x, float* y, int32_t outer, int32_t di, i
 size_t mri3d_surface_distance_workspace_bytes(int32_t d, int32_t h, int32_t w);
 int mri3d_surface_distance(const uint8_t* gt, const uint8_t* pred, int32_t d, int32_t h, int32_t w,
                            const double* area_table, double* sums, void* workspace, size_t ws_bytes, mri3d_stream_t stream);
+/* The surface-element lists behind compute_surface_distances (segmentation/metrics.py:25-178), for the order-dependent metrics
+ * (compute_robust_hausdorff, compute_surface_overlap_at_tolerance, compute_surface_dice_at_tolerance, metrics.py:208-310):
+ * per direction, the exact squared distance of every surface element to the other surface (>= 0x3f000000: the other mask
+ * has no surface) and its neighbour code, in arbitrary order; counts[0], counts[1] (device) = list lengths (entries beyond
+ * `capacity` are dropped: size the lists for (d+1)(h+1)(w+1) to be safe).  Same workspace as mri3d_surface_distance. */
+int mri3d_surface_elements(const uint8_t* gt, const uint8_t* pred, int32_t d, int32_t h, int32_t w, int32_t* d2_gt,
+                           uint8_t* code_gt, int32_t* d2_pred, uint8_t* code_pred, int64_t capacity, uint64_t* counts,
+                           void* workspace, size_t ws_bytes, mri3d_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Channel-slice plumbing: torch.cat along channels (unet.UNet decoder, modified_3dunet.py:158-178) and

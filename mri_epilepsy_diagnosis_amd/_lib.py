@@ -80,6 +80,7 @@ SIGNATURES = {
     "mri3d_crop_or_pad_f32": (c_int32, [_P, _P, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_float, _P]),
     "mri3d_surface_distance_workspace_bytes": (c_size_t, [c_int32, c_int32, c_int32]),
     "mri3d_surface_distance": (c_int32, [_P, _P, c_int32, c_int32, c_int32, _P, _P, _P, c_size_t, _P]),
+    "mri3d_surface_elements": (c_int32, [_P, _P, c_int32, c_int32, c_int32, _P, _P, _P, _P, c_int64, _P, _P, c_size_t, _P]),
     "mri3d_copy_channels": (c_int32, [_P, _P, c_int64, c_int32, c_int32, c_int32, c_int32, _P]),
     "mri3d_add_channels": (c_int32, [_P, _P, _P, c_int64, c_int32, c_int32, c_int32, c_int32, c_int32, _P]),
     "mri3d_convert_channels": (c_int32, [_P, c_int32, _P, c_int32, c_int64, c_int32, c_int32, c_int32, _P]),

@@ -102,6 +102,32 @@ sd_reduce_kernel(const uint8_t* __restrict__ code_self, const int* __restrict__ 
         part[(size_t)blockIdx.x * 2 + threadIdx.x] = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
 }
 
+// append (squared distance to the other surface, neighbour code) of every surface element of `code_self`; the order of the
+// list is arbitrary (atomic cursor) — the host sorts it the way the reference does
+__global__ void __launch_bounds__(256)
+sd_collect_kernel(const uint8_t* __restrict__ code_self, const int* __restrict__ f_other, long long total,
+                  int* __restrict__ out_d2, uint8_t* __restrict__ out_code, unsigned long long* __restrict__ cursor,
+                  long long capacity) {
+    const int lane = threadIdx.x & 63;
+    for (long long base = (long long)blockIdx.x * blockDim.x; base < total; base += (long long)gridDim.x * blockDim.x) {
+        const long long p = base + threadIdx.x;
+        const uint8_t c = p < total ? code_self[p] : (uint8_t)0;
+        const bool hit = is_border(c);
+        const unsigned long long m = __ballot(hit);
+        if (m == 0ull) continue;   // wave-uniform
+        unsigned long long start = 0;
+        if (lane == __ffsll((long long)m) - 1) start = atomicAdd(cursor, (unsigned long long)__popcll(m));
+        start = __shfl(start, __ffsll((long long)m) - 1, 64);
+        if (hit) {
+            const long long idx = (long long)start + __popcll(m & ((1ull << lane) - 1ull));
+            if (idx < capacity) {
+                out_d2[idx] = f_other[p];
+                out_code[idx] = c;
+            }
+        }
+    }
+}
+
 __global__ void sd_finalize_kernel(const double* __restrict__ part, int nblk, double* __restrict__ out2) {
     if (threadIdx.x >= 2) return;
     double s = 0.0;
@@ -158,4 +184,47 @@ extern "C" int mri3d_surface_distance(const uint8_t* gt, const uint8_t* pred, in
         hipLaunchKernelGGL(sd_finalize_kernel, dim3(1), dim3(64), 0, s, part, nblk, sums + 2 * dir);
     }
     return check_launch("surface_distance");
+}
+
+/* Surface-element lists for the order-dependent metrics of segmentation/metrics.py:208-310 (robust Hausdorff, surface overlap /
+ * surface Dice at a tolerance): for each direction every surface element's squared distance (exact integer; >= 0x3f000000 =
+ * the other mask has no surface) and neighbour code, in arbitrary order; counts[dir] = number of elements (device uint64). */
+extern "C" int mri3d_surface_elements(const uint8_t* gt, const uint8_t* pred, int32_t d, int32_t h, int32_t w, int32_t* d2_gt,
+                                      uint8_t* code_gt, int32_t* d2_pred, uint8_t* code_pred, int64_t capacity,
+                                      uint64_t* counts, void* workspace, size_t ws_bytes, mri3d_stream_t stream) {
+    MRI3D_REQUIRE(gt && pred && d2_gt && code_gt && d2_pred && code_pred && counts && capacity > 0 && d > 0 && h > 0 && w > 0,
+                  MRI3D_EINVAL, "surface_elements: bad arguments");
+    MRI3D_REQUIRE((int64_t)(d + 1) * (h + 1) * (w + 1) < 0x7fffffffLL && d < 32768 && h < 32768 && w < 32768, MRI3D_ENOTSUP,
+                  "surface_elements: volume too large");
+    MRI3D_REQUIRE(workspace && ws_bytes >= mri3d_surface_distance_workspace_bytes(d, h, w) &&
+                      (reinterpret_cast<uintptr_t>(workspace) & 7) == 0,
+                  MRI3D_EWORKSPACE, "surface_elements: workspace %zu < %zu", ws_bytes,
+                  mri3d_surface_distance_workspace_bytes(d, h, w));
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int Dc = d + 1, Hc = h + 1, Wc = w + 1;
+    const long long nc = (long long)Dc * Hc * Wc;
+    char* base = static_cast<char*>(workspace);
+    base += align_up((size_t)kSdBlocks * 2 * sizeof(double), 256);
+    int* fa = reinterpret_cast<int*>(base);
+    int* fb = fa + nc;
+    int* fc = fb + nc;
+    uint8_t* cg = reinterpret_cast<uint8_t*>(fc + nc);
+    uint8_t* cp = cg + align_up((size_t)nc, 256);
+    const int grid = stream_grid(nc, 256);
+    if (hipMemsetAsync(counts, 0, 2 * sizeof(uint64_t), s) != hipSuccess) {
+        set_error("surface_elements: hipMemsetAsync failed");
+        return MRI3D_ELAUNCH;
+    }
+    hipLaunchKernelGGL(sd_codes_kernel, dim3(grid), dim3(256), 0, s, gt, pred, cg, cp, d, h, w);
+    for (int dir = 0; dir < 2; ++dir) {
+        const uint8_t* other = dir == 0 ? cp : cg;
+        const uint8_t* self = dir == 0 ? cg : cp;
+        hipLaunchKernelGGL(sd_edt_w_kernel, dim3(grid), dim3(256), 0, s, other, fa, Dc, Hc, Wc);
+        hipLaunchKernelGGL(sd_edt_axis_kernel, dim3(grid), dim3(256), 0, s, fa, fb, nc, (long long)Wc, Hc);
+        hipLaunchKernelGGL(sd_edt_axis_kernel, dim3(grid), dim3(256), 0, s, fb, fc, nc, (long long)Wc * Hc, Dc);
+        hipLaunchKernelGGL(sd_collect_kernel, dim3(grid), dim3(256), 0, s, self, fc, nc, dir == 0 ? d2_gt : d2_pred,
+                           dir == 0 ? code_gt : code_pred, reinterpret_cast<unsigned long long*>(counts) + dir,
+                           (long long)capacity);
+    }
+    return check_launch("surface_elements");
 }

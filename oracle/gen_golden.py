@@ -347,8 +347,28 @@ def surface_asd():
         b = np.zeros((32, 32, 32), np.uint8); b[6:22, 4:20, 4:20] = 1
         cube = R_MET.compute_average_surface_distance(R_MET.compute_surface_distances(a.astype(bool), b.astype(bool), (1, 1, 1)))
         assert abs(cube[0] - 0.671674) < 1e-6 and np.allclose(cube, O_MET.average_surface_distance(a, b, area), rtol=1e-12)
+    # order-dependent metrics (metrics.py:208-310): robust Hausdorff 95, surface overlap / Dice at 1 mm — reference values, and
+    # the oracle's sorted lists must equal the reference's element for element
+    hd95, sdice, overlap, nsurf = [], [], [], []
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        for seed, shape in cases:
+            gt, pred = O_MET.seeded_blobs(seed, shape)
+            rs = R_MET.compute_surface_distances(gt.astype(bool), pred.astype(bool), (1, 1, 1))
+            os_ = O_MET.surface_distances(gt, pred, area)
+            for key in rs:
+                assert np.array_equal(rs[key], os_[key]), key
+            hd95.append(R_MET.compute_robust_hausdorff(rs, 95))
+            sdice.append(R_MET.compute_surface_dice_at_tolerance(rs, 1))
+            overlap.append(R_MET.compute_surface_overlap_at_tolerance(rs, 1))
+            nsurf.append((len(rs["distances_gt_to_pred"]), len(rs["distances_pred_to_gt"])))
+            assert hd95[-1] == O_MET.robust_hausdorff(os_, 95) and sdice[-1] == O_MET.surface_dice_at_tolerance(os_, 1)
+        rs = R_MET.compute_surface_distances(a.astype(bool), b.astype(bool), (1, 1, 1))
+        cube_hd95, cube_sdice = R_MET.compute_robust_hausdorff(rs, 95), R_MET.compute_surface_dice_at_tolerance(rs, 1)
+        assert cube_hd95 == 2.0 and abs(cube_sdice - 0.704335) < 1e-6       # SURVEY Appendix D known answers
     np.savez(os.path.join(OUT, "surface_asd.npz"), cases=np.array([(c[0],) + c[1] for c in cases]), asd=np.array(ref_vals),
-             cube_asd=np.array(cube), area_table=area)
+             cube_asd=np.array(cube), area_table=area, hd95=np.array(hd95), sdice1=np.array(sdice), overlap1=np.array(overlap),
+             nsurf=np.array(nsurf), cube_hd95=np.array(cube_hd95), cube_sdice1=np.array(cube_sdice))
     print("surface asd ok", ref_vals, cube)
 
 

@@ -68,3 +68,43 @@ def seeded_blobs(seed, shape, thr_gt=0.0, thr_pred=0.15):
     f /= f.std()
     g /= g.std()
     return (f > thr_gt).astype(np.uint8), (g > thr_pred).astype(np.uint8)
+
+
+def surface_distances(mask_gt, mask_pred, area_table):
+    """compute_surface_distances (metrics.py:25-178, unit spacing) restated with scipy: the sorted distance / area lists."""
+    from scipy import ndimage
+    code_g, bord_g = surface_elements(mask_gt)
+    code_p, bord_p = surface_elements(mask_pred)
+    if not (np.asarray(mask_gt).any() or np.asarray(mask_pred).any()):
+        e = np.array([])
+        return {"distances_gt_to_pred": e, "distances_pred_to_gt": e, "surfel_areas_gt": e, "surfel_areas_pred": e}
+    dist_g = ndimage.distance_transform_edt(~bord_g) if bord_g.any() else np.inf * np.ones(bord_g.shape)
+    dist_p = ndimage.distance_transform_edt(~bord_p) if bord_p.any() else np.inf * np.ones(bord_p.shape)
+    out = {}
+    for name, key, d, a in (("gt_to_pred", "gt", dist_p[bord_g], area_table[code_g][bord_g]),
+                            ("pred_to_gt", "pred", dist_g[bord_p], area_table[code_p][bord_p])):
+        if d.shape != (0,):
+            srt = np.array(sorted(zip(d, a)))
+            d, a = srt[:, 0], srt[:, 1]
+        out["distances_" + name] = d
+        out["surfel_areas_" + key] = a
+    return out
+
+
+def robust_hausdorff(sd, percent):
+    """metrics.py:208-247."""
+    res = []
+    for dist, area in ((sd["distances_gt_to_pred"], sd["surfel_areas_gt"]), (sd["distances_pred_to_gt"], sd["surfel_areas_pred"])):
+        if len(dist) > 0:
+            cum = np.cumsum(area) / np.sum(area)
+            res.append(dist[min(np.searchsorted(cum, percent / 100.0), len(dist) - 1)])
+        else:
+            res.append(np.inf)
+    return max(res)
+
+
+def surface_dice_at_tolerance(sd, tol):
+    """metrics.py:280-309."""
+    og = np.sum(sd["surfel_areas_gt"][sd["distances_gt_to_pred"] <= tol])
+    op = np.sum(sd["surfel_areas_pred"][sd["distances_pred_to_gt"] <= tol])
+    return (og + op) / (np.sum(sd["surfel_areas_gt"]) + np.sum(sd["surfel_areas_pred"]))

@@ -415,3 +415,37 @@ def test_surface_distance_device_vs_oracle_and_reference_golden():
     gt, pred = O_MET.seeded_blobs(5, (160, 192, 160))
     got = surface.average_surface_distance(torch.from_numpy(gt).cuda(), torch.from_numpy(pred).cuda())
     assert np.allclose(got, O_MET.average_surface_distance(gt, pred, area), rtol=1e-12, atol=0)
+
+
+def test_surface_element_lists_and_order_metrics_bit_exact():
+    """§8(f4): the device's surface-element lists (exact squared distances + neighbour codes), sorted the reference's way, must
+    EQUAL the oracle's lists element for element; robust Hausdorff 95, surface overlap and surface Dice at 1 mm computed from
+    them are then bit-identical to the reference's values (tests/golden/surface_asd.npz), SURVEY's known answers included."""
+    import numpy as np
+    from mri_epilepsy_diagnosis_amd.segmentation import surface
+    from oracle import metrics as O_MET
+    from util import load_golden
+    g = load_golden("surface_asd.npz")
+    area = g["area_table"]
+    for row, hd, sdc, ov, asd in zip(g["cases"], g["hd95"], g["sdice1"], g["overlap1"], g["asd"]):
+        gt, pred = O_MET.seeded_blobs(int(row[0]), tuple(int(v) for v in row[1:]))
+        sd = surface.surface_distances(torch.from_numpy(gt).cuda(), torch.from_numpy(pred).cuda())
+        ref = O_MET.surface_distances(gt, pred, area)
+        for key in ref:
+            assert np.array_equal(sd[key], ref[key]), key
+        assert surface.compute_robust_hausdorff(sd, 95) == hd
+        assert surface.compute_surface_dice_at_tolerance(sd, 1) == sdc
+        assert np.array_equal(surface.compute_surface_overlap_at_tolerance(sd, 1), ov)
+        assert np.array_equal(surface.compute_average_surface_distance(sd), asd)          # bit-exact through the sorted lists
+    a = np.zeros((32, 32, 32), np.uint8); a[4:20, 4:20, 4:20] = 1
+    b = np.zeros((32, 32, 32), np.uint8); b[6:22, 4:20, 4:20] = 1
+    sd = surface.surface_distances(torch.from_numpy(a).cuda(), torch.from_numpy(b).cuda())
+    assert surface.compute_robust_hausdorff(sd, 95) == 2.0
+    assert surface.compute_surface_dice_at_tolerance(sd, 1) == float(g["cube_sdice1"])
+    # one empty mask: inf distances; both empty: empty lists
+    z = np.zeros((6, 7, 8), np.uint8)
+    sd = surface.surface_distances(torch.from_numpy(np.ascontiguousarray(a[:6, :7, :8] | 1)).cuda(), torch.from_numpy(z).cuda())
+    assert len(sd["distances_pred_to_gt"]) == 0 and np.isinf(sd["distances_gt_to_pred"]).all()
+    assert surface.compute_robust_hausdorff(sd, 95) == np.inf
+    sd = surface.surface_distances(torch.from_numpy(z).cuda(), torch.from_numpy(z).cuda())
+    assert all(len(v) == 0 for v in sd.values())

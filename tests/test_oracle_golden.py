@@ -217,3 +217,23 @@ def test_surface_asd_oracle_matches_reference_golden():
     b = np.zeros((32, 32, 32), np.uint8); b[6:22, 4:20, 4:20] = 1
     got = O_MET.average_surface_distance(a, b, area)
     assert np.allclose(got, g["cube_asd"], rtol=1e-12) and abs(got[0] - 0.671674) < 1e-6
+
+
+def test_surface_order_metrics_oracle_matches_reference_golden():
+    """Robust Hausdorff 95 / surface Dice at 1 mm of the oracle against the reference's compute_robust_hausdorff /
+    compute_surface_dice_at_tolerance (tests/golden/surface_asd.npz) — bit-exact, incl. SURVEY's known answers."""
+    import numpy as np
+    from oracle import metrics as O_MET
+    from util import load_golden
+    g = load_golden("surface_asd.npz")
+    area = g["area_table"]
+    for row, hd, sdc, ns in zip(g["cases"], g["hd95"], g["sdice1"], g["nsurf"]):
+        gt, pred = O_MET.seeded_blobs(int(row[0]), tuple(int(v) for v in row[1:]))
+        sd = O_MET.surface_distances(gt, pred, area)
+        assert (len(sd["distances_gt_to_pred"]), len(sd["distances_pred_to_gt"])) == tuple(ns)
+        assert O_MET.robust_hausdorff(sd, 95) == hd and O_MET.surface_dice_at_tolerance(sd, 1) == sdc
+    a = np.zeros((32, 32, 32), np.uint8); a[4:20, 4:20, 4:20] = 1
+    b = np.zeros((32, 32, 32), np.uint8); b[6:22, 4:20, 4:20] = 1
+    sd = O_MET.surface_distances(a, b, area)
+    assert O_MET.robust_hausdorff(sd, 95) == 2.0 == float(g["cube_hd95"])
+    assert O_MET.surface_dice_at_tolerance(sd, 1) == float(g["cube_sdice1"]) and abs(float(g["cube_sdice1"]) - 0.704335) < 1e-6
