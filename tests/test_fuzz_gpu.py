@@ -1,0 +1,72 @@
+"""Seeded random-geometry sweep of the 3x3x3 MFMA conv kernels (fp32 and bf16 storage): ragged spatial sizes around the tile
+edges (4x8x16 forward tile, 2x6x16 / 2x6x32 weight-gradient tiles), every channel count the dispatcher routes to an MFMA
+kernel, pitched (channel-slice) inputs and outputs — against torch's CPU conv on the same (rounded) inputs."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from mri_epilepsy_diagnosis_amd import ops
+
+pytestmark = pytest.mark.gpu
+
+
+def _cases(n, seed):
+    rng = np.random.Generator(np.random.PCG64(seed))
+    chans = [8, 16, 24, 32, 48, 64]
+    out = []
+    for _ in range(n):
+        ci, co = int(rng.choice(chans)), int(rng.choice(chans))
+        d, h, w = int(rng.integers(1, 11)), int(rng.integers(1, 15)), int(rng.integers(1, 40))
+        nb = int(rng.integers(1, 3))
+        pad_in, pad_out = int(rng.choice([0, 8, 16])), int(rng.choice([0, 8]))
+        out.append((nb, ci, co, d, h, w, pad_in, pad_out, int(rng.integers(0, 1 << 30))))
+    return out
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
+@pytest.mark.parametrize("case", _cases(14, 2024), ids=lambda c: "n%d_%d-%d_%dx%dx%d_p%d_%d" % c[:8])
+def test_conv3x3x3_random_geometry(case, dtype):
+    nb, ci, co, d, h, w, pad_in, pad_out, seed = case
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(nb, ci, d, h, w, generator=g)
+    wt = torch.randn(co, ci, 3, 3, 3, generator=g) * (1.0 / np.sqrt(27 * ci))
+    b = torch.randn(co, generator=g)
+    dy = torch.randn(nb, co, d, h, w, generator=g)
+    if dtype == torch.bfloat16:
+        x, dy = x.to(dtype).float(), dy.to(dtype).float()
+    # input as a channel slice of a wider NDHWC buffer (voxel pitch ci + pad_in), as the decoder's concat buffers are
+    xbuf = torch.zeros(nb, ci + pad_in, d, h, w, device="cuda", dtype=dtype).contiguous(memory_format=torch.channels_last_3d)
+    xbuf[:, pad_in:] = x.cuda().to(dtype)
+    xg = xbuf[:, pad_in:].detach().requires_grad_(True)
+    wg, bg = wt.cuda().requires_grad_(True), b.cuda().requires_grad_(True)
+    yg = ops.conv3d(xg, wg, bg, padding=1)
+    dybuf = torch.zeros(nb, co + pad_out, d, h, w, device="cuda", dtype=dtype).contiguous(memory_format=torch.channels_last_3d)
+    dybuf[:, :co] = dy.cuda().to(dtype)
+    yg.backward(dybuf[:, :co])
+
+    def ref(wref):
+        xr = x.clone().requires_grad_(True)
+        wr, br = wref.clone().requires_grad_(True), b.clone().requires_grad_(True)
+        yr = F.conv3d(xr, wr, br, padding=1)
+        yr.backward(dy)
+        return yr.detach(), xr.grad, wr.grad, br.grad
+
+    if dtype == torch.float32:
+        yr, dxr, dwr, dbr = ref(wt)
+        tol_act = tol_par = 2e-5
+    else:
+        # forward / data-gradient round the weights to bf16 for the MFMA operands; the weight gradient does not involve them
+        yr, dxr, _, _ = ref(wt.to(dtype).float())
+        _, _, dwr, dbr = ref(wt)
+        tol_act, tol_par = 1.2e-2, 2e-3
+
+    def close(a, r, tol, what):
+        a, r = a.detach().float().cpu(), r.float()
+        err = (a - r).abs().max().item()
+        assert err <= tol * (r.abs().max().item() + 1e-6), "%s: %.3e vs scale %.3e" % (what, err, r.abs().max().item())
+
+    close(yg, yr, tol_act, "y")
+    close(xg.grad, dxr, tol_act, "dx")
+    close(wg.grad, dwr, tol_par, "dw")
+    close(bg.grad, dbr, tol_par, "db")
