@@ -222,6 +222,30 @@ int mri3d_surface_elements(const uint8_t* gt, const uint8_t* pred, int32_t d, in
                            void* workspace, size_t ws_bytes, mri3d_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * Patch pipeline: the windows TorchIO cuts for patch training and grid inference
+ * (torchio.Queue + torchio.sampler.ImageSampler, segmentation/routine.py:150-178 and pretraining_3d_unet.ipynb cell 24;
+ * torchio.inference.GridSampler / GridAggregator.add_batch(labels, locations), pretraining_3d_unet.ipynb cell 26).
+ * Third-party arithmetic, restated in oracle/patches.py ("parity unpinned").  Volumes are `nvol` contiguous (d,h,w) arrays
+ * of `elem_bytes`-sized elements in HBM; `loc_host` is a HOST table of npatch x 4 int32 = (volume index, d0, h0, w0), checked
+ * here against the volume (MRI3D_EINVAL when a window leaves it) and handed to the kernels by value.
+ *   extract_patches:          out[p, z, y, x] = volumes[loc[p].vol, d0+z, h0+y, w0+x]
+ *   aggregate_patches_u8:     each (pd,ph,pw) uint8 label window is cropped by `border` voxels on all six faces and written
+ *                             to out[vol] at its location, in patch order: where cropped windows overlap the later patch
+ *                             wins (what sequential add_batch slicing does); voxels no cropped window covers are untouched.
+ *   aggregate_patches_argmax: the same, reading logits [p][z][y][x][ld] and taking argmax over c channels in flight
+ *                             (labels = logits.argmax(dim=1, keepdim=True); first maximum wins).
+ * ---------------------------------------------------------------------------------------------- */
+int mri3d_extract_patches(const void* volumes, int32_t elem_bytes, int32_t nvol, int32_t d, int32_t h, int32_t w,
+                          const int32_t* loc_host, int32_t npatch, int32_t pd, int32_t ph, int32_t pw, void* out,
+                          mri3d_stream_t stream);
+int mri3d_aggregate_patches_u8(const uint8_t* patches, const int32_t* loc_host, int32_t npatch, int32_t pd, int32_t ph,
+                               int32_t pw, int32_t bd, int32_t bh, int32_t bw, uint8_t* out, int32_t nvol, int32_t d,
+                               int32_t h, int32_t w, mri3d_stream_t stream);
+int mri3d_aggregate_patches_argmax(const void* logits, int32_t c, int32_t ld, int32_t dtype, const int32_t* loc_host,
+                                   int32_t npatch, int32_t pd, int32_t ph, int32_t pw, int32_t bd, int32_t bh, int32_t bw,
+                                   uint8_t* out, int32_t nvol, int32_t d, int32_t h, int32_t w, mri3d_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Channel-slice plumbing: torch.cat along channels (unet.UNet decoder, modified_3dunet.py:158-178) and
  * residual adds (modified_3dunet.py:108, cnn_model.py:34).
  *   copy: dst[v, 0:c] = src[v, 0:c]      add: dst[v, 0:c] = a[v,0:c] + b[v,0:c]

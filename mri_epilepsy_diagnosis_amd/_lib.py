@@ -81,6 +81,12 @@ SIGNATURES = {
     "mri3d_surface_distance_workspace_bytes": (c_size_t, [c_int32, c_int32, c_int32]),
     "mri3d_surface_distance": (c_int32, [_P, _P, c_int32, c_int32, c_int32, _P, _P, _P, c_size_t, _P]),
     "mri3d_surface_elements": (c_int32, [_P, _P, c_int32, c_int32, c_int32, _P, _P, _P, _P, c_int64, _P, _P, c_size_t, _P]),
+    "mri3d_extract_patches": (c_int32, [_P, c_int32, c_int32, c_int32, c_int32, c_int32, _P, c_int32, c_int32, c_int32,
+                                        c_int32, _P, _P]),
+    "mri3d_aggregate_patches_u8": (c_int32, [_P, _P, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, _P,
+                                             c_int32, c_int32, c_int32, c_int32, _P]),
+    "mri3d_aggregate_patches_argmax": (c_int32, [_P, c_int32, c_int32, c_int32, _P, c_int32, c_int32, c_int32, c_int32,
+                                                 c_int32, c_int32, c_int32, _P, c_int32, c_int32, c_int32, c_int32, _P]),
     "mri3d_copy_channels": (c_int32, [_P, _P, c_int64, c_int32, c_int32, c_int32, c_int32, _P]),
     "mri3d_add_channels": (c_int32, [_P, _P, _P, c_int64, c_int32, c_int32, c_int32, c_int32, c_int32, _P]),
     "mri3d_convert_channels": (c_int32, [_P, c_int32, _P, c_int32, c_int64, c_int32, c_int32, c_int32, _P]),
