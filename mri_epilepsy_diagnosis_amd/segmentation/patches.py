@@ -237,8 +237,13 @@ class ImageSampler:
     def __iter__(self):
         return self
 
+    def draw(self, n):
+        """int64 [n, 3] window origins in one call of the generator."""
+        hi = np.asarray(self.shape, dtype=np.int64) - np.asarray(self.patch_size, dtype=np.int64) + 1
+        return self.rng.integers(0, hi, size=(int(n), 3))
+
     def __next__(self):
-        return tuple(int(self.rng.integers(0, s - p + 1)) for s, p in zip(self.shape, self.patch_size))
+        return tuple(int(v) for v in self.draw(1)[0])
 
 
 class Queue:
@@ -276,7 +281,7 @@ class Queue:
                                      % (tuple(v.shape), shape0))
             self._resident[name] = torch.cat(vols, dim=0).contiguous()  # (S, D, H, W) in HBM
         self.shape = shape0[1:]
-        self.patches_list = []  # (subject index, d0, h0, w0)
+        self.patches_list = np.empty((0, 4), dtype=np.int32)  # (subject index, d0, h0, w0); popped from the end
         self._order, self._next = [], 0
 
     def __len__(self):
@@ -293,22 +298,31 @@ class Queue:
 
     def fill(self):
         n_subjects = min(self.max_length // self.samples_per_volume, len(self.subjects))
-        for _ in range(n_subjects):
-            s = self._next_subject()
-            sampler = iter(self.sampler_class(self.shape, self.patch_size, self.rng))
-            for _ in range(self.samples_per_volume):
-                self.patches_list.append((s,) + tuple(next(sampler)))
+        spv = self.samples_per_volume
+        new = np.empty((n_subjects * spv, 4), dtype=np.int32)
+        for i in range(n_subjects):
+            sampler = self.sampler_class(self.shape, self.patch_size, self.rng)
+            new[i * spv:(i + 1) * spv, 0] = self._next_subject()
+            if hasattr(sampler, "draw"):
+                new[i * spv:(i + 1) * spv, 1:] = sampler.draw(spv)
+            else:
+                it = iter(sampler)
+                for j in range(spv):
+                    new[i * spv + j, 1:] = next(it)
+        self.patches_list = np.concatenate([self.patches_list, new])
         if self.shuffle_patches:
-            perm = self.rng.permutation(len(self.patches_list))
-            self.patches_list = [self.patches_list[i] for i in perm]
+            self.patches_list = self.patches_list[self.rng.permutation(len(self.patches_list))]
 
     def _pop(self, n):
-        table = np.empty((n, 4), dtype=np.int32)
-        for i in range(n):
-            if not self.patches_list:
+        parts, need = [], n
+        while need > 0:
+            if len(self.patches_list) == 0:
                 self.fill()
-            table[i] = self.patches_list.pop()
-        return table
+            k = min(need, len(self.patches_list))
+            parts.append(self.patches_list[len(self.patches_list) - k:][::-1])  # pop() order: last first
+            self.patches_list = self.patches_list[:len(self.patches_list) - k]
+            need -= k
+        return np.ascontiguousarray(np.concatenate(parts))
 
     def _cut(self, table):
         out = {name: {DATA: extract_patches(v, table, self.patch_size)} for name, v in self._resident.items()}

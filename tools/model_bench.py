@@ -4,6 +4,8 @@
   m3d   Modified3DUNet(1,2,8), batch 1 x 160x192x160, soft-Dice step
   cfg4  unet.UNet(c0=8) under the bf16 autocast region, batch 2 x 160x192x160 per GPU (configs[3]'s per-GPU share);
         cfg2 = the same step in fp32 for the side-by-side
+  patch16  the reference's patch training (pretraining_3d_unet.ipynb cells 24-25): U-Net c0=16 (c8: c0=8) on batches of
+        16 random 64^3 windows cut from HBM-resident subjects by segmentation/patches.py
 Prints ms/step, units/s and the per-operator device-time table (top N)."""
 import os
 import sys
@@ -26,7 +28,7 @@ if which == "all":
     # later steps (full-AE step 23 ms in sequence vs 10.3 ms on its own)
     import subprocess
     rc = 0
-    for cfg in ("cfg3", "cfg3ae", "cfg5", "m3d", "m3d_graph", "cfg2", "cfg4"):
+    for cfg in ("cfg3", "cfg3ae", "cfg5", "m3d", "m3d_graph", "patch16", "patch16_c8", "cfg2", "cfg4"):
         rc |= subprocess.run([sys.executable, os.path.abspath(__file__), cfg]).returncode
     sys.exit(rc)
 dev = torch.device("cuda")
@@ -120,6 +122,36 @@ if which == "m3d_graph":
         cap.run()
         fopt.step(flat.all_reduce())
     run("Modified3DUNet(1,2,8) dice step, hipGraph fwd+bwd, 1 x 160x192x160", 1, step6g)
+for tag, c0 in (("patch16", 16), ("patch16_c8", 8)):
+    # patch training of pretraining_3d_unet.ipynb cells 24-25: get_model_and_optimizer's U-Net (c0=16), batches of 16 random
+    # 64^3 windows from the HBM-resident queue (segmentation/patches.py), soft-Dice step; the queue pop + 2 extract launches
+    # are inside the timed step
+    if which != tag:
+        continue
+    from mri_epilepsy_diagnosis_amd import parallel
+    from mri_epilepsy_diagnosis_amd.segmentation import patches as PT
+    from mri_epilepsy_diagnosis_amd.unet import UNet
+    torch.manual_seed(0)
+    net = UNet(in_channels=1, out_classes=2, dimensions=3, num_encoding_blocks=3, out_channels_first_layer=c0,
+               normalization="batch", upsampling_type="linear", padding=True, activation="PReLU").to(dev)
+    flat = parallel.FlatParams(net)
+    fopt = parallel.FlatAdam(flat, lr=1e-3, weight_decay=0.01, decoupled=True)
+    subjects = [{PT.MRI: {PT.DATA: torch.randn(1, 160, 192, 160, device=dev, generator=g)},
+                 PT.LABEL: {PT.DATA: (torch.rand(1, 160, 192, 160, device=dev, generator=g) < 0.1).float()}}
+                for _ in range(30)]
+    queue = PT.Queue(subjects, max_length=240, samples_per_volume=8, patch_size=64, seed=0)
+    state = {"it": queue.batches(16)}
+
+    def step8():
+        try:
+            b = next(state["it"])
+        except StopIteration:
+            state["it"] = queue.batches(16)
+            b = next(state["it"])
+        flat.zero_grad()
+        ops.softmax_dice_loss(net(b[PT.MRI][PT.DATA]), b[PT.LABEL][PT.DATA]).backward()
+        fopt.step(flat.all_reduce())
+    run("%s unet.UNet(c0=%d) fp32 dice step on queue batches of 16 x 64^3 windows" % (tag, c0), 16, step8)
 for tag, use_bf16 in (("cfg2", False), ("cfg4", True)):
     if which != tag:
         continue
