@@ -418,6 +418,142 @@ upsample2x_bwd_kernel(Mri3dUpGeom g, const T* __restrict__ dy, T* __restrict__ d
     }
 }
 
+// ------------------------------------------------------------------ trilinear x2 backward, marching along D
+// The tile kernel above re-reads its fine halo in all three axes ((6*6*34)/(4*4*32) = 2.4x for the 2x2x16 tile; PMC:
+// 2.9 GB fetched for the 1.26 GB gradient of the 32-channel level).  The transposed interpolation is separable, so this
+// kernel walks a 4x16 coarse column along D: one fine PLANE tile (10 x 34 voxels x 16 channels, fp32) at a time goes
+// through LDS (double-buffered, the next plane's pieces are in flight while this one is reduced), every lane folds the 4x4
+// in-plane taps of its (coarse h, w, channel quad) into one value S_f, and the D taps are a running sum in registers:
+//   dx[i] = wd_i[0] S_{2i-1} + wd_i[1] S_{2i} + wd_i[2] S_{2i+1} + wd_i[3] S_{2i+2}
+// so a fine plane is read once per column segment (halo only in H and W: 1.33x, plus 2 planes per MD-plane segment).
+constexpr int MTH = 4, MTW = 16, MCQ = 4, MD = 8;            // coarse tile h x w, channel quads per pass, coarse planes per item
+constexpr int MFH = 2 * MTH + 2, MFW = 2 * MTW + 2, MPV = MFH * MFW * MCQ;   // 1360 16-byte pieces per fine plane
+constexpr int MNP = (MPV + 255) / 256;                       // 6 pieces per lane
+
+template <typename T>
+__global__ void __launch_bounds__(256)
+upsample2x_bwd_march_kernel(Mri3dUpGeom g, const T* __restrict__ dy, T* __restrict__ dx, int segsD, int tilesH, int tilesW,
+                            int cpasses, int nitems) {
+    __shared__ float4 pbuf[2][MPV];   // 2 x 21.25 KB
+    const int tid = threadIdx.x;
+    const int q = tid % MCQ, v = tid / MCQ;
+    const int iwl = v % MTW, ihl = v / MTW;
+    // blockIdx -> item: consecutive workgroups land on different XCDs, so each XCD gets one contiguous range of items
+    // (neighbouring tiles share their H/W halo through that XCD's L2)
+    const int per_xcd = (nitems + 7) / 8;
+    for (int b = blockIdx.x; b < per_xcd * 8; b += gridDim.x) {
+        const int item = (b % 8) * per_xcd + b / 8;
+        if (item >= nitems) continue;   // uniform per workgroup
+        // channel pass fastest: the passes of one tile read the two halves of the same 128-byte lines, so they run side by
+        // side on one XCD and the second reader hits its L2 (32-channel level, 2 x 80x96x80 coarse: 0.60 ms with the passes 120 items apart, 0.37 ms side by side; tile kernel 0.94 ms)
+        int t = item;
+        const int c0 = (t % cpasses) * (4 * MCQ);
+        t /= cpasses;
+        const int w0 = (t % tilesW) * MTW;
+        t /= tilesW;
+        const int h0 = (t % tilesH) * MTH;
+        t /= tilesH;
+        const int d0 = (t % segsD) * MD;
+        const int n = t / segsD;
+        const int d1 = min(d0 + MD, g.di);   // coarse planes [d0, d1)
+        const T* dn = dy + (int64_t)n * g.dout * g.ho * g.wo * g.y_ld + c0;
+        const int64_t plane = (int64_t)g.ho * g.wo * g.y_ld;
+        const int ih = h0 + ihl, iw = w0 + iwl;
+        const bool vok = ih < g.hi && iw < g.wi && c0 + 4 * q < g.c;
+        float wh[4], ww[4];
+        up2_axis_weights(ih, g.hi, wh);
+        up2_axis_weights(iw, g.wi, ww);
+        // this lane's pieces of a plane tile: element offset inside the plane (clamped, so the load is always legal) + mask
+        int poff[MNP];
+        unsigned pok = 0;
+#pragma unroll
+        for (int j = 0; j < MNP; ++j) {
+            const int idx = j * 256 + tid;
+            const int qq = idx % MCQ, fv = idx / MCQ;
+            const int fw = fv % MFW, fh = fv / MFW;
+            const int oh = 2 * h0 - 1 + fh, ow = 2 * w0 - 1 + fw;
+            const bool ok = idx < MPV && (unsigned)oh < (unsigned)g.ho && (unsigned)ow < (unsigned)g.wo && c0 + 4 * qq < g.c;
+            pok |= ok ? (1u << j) : 0u;
+            const int ch = min(max(oh, 0), g.ho - 1), cw = min(max(ow, 0), g.wo - 1);
+            poff[j] = (ch * g.wo + cw) * g.y_ld + (c0 + 4 * qq < g.c ? 4 * qq : 0);
+        }
+        const int f0 = max(2 * d0 - 1, 0), f1 = min(2 * d1, g.dout - 1);   // fine planes [f0, f1] feed coarse [d0, d1)
+        float4 pv[MNP];
+        auto fetch = [&](int f) {
+            const T* pl = dn + (int64_t)f * plane;
+#pragma unroll
+            for (int j = 0; j < MNP; ++j) pv[j] = ldf4(pl + poff[j]);
+        };
+        auto stash = [&](int buf) {
+#pragma unroll
+            for (int j = 0; j < MNP; ++j) {
+                const int idx = j * 256 + tid;
+                const bool ok = (pok >> j) & 1u;
+                float4 val;
+                val.x = ok ? pv[j].x : 0.f; val.y = ok ? pv[j].y : 0.f; val.z = ok ? pv[j].z : 0.f; val.w = ok ? pv[j].w : 0.f;
+                if (j < MNP - 1 || idx < MPV) pbuf[buf][idx] = val;
+            }
+        };
+        __syncthreads();   // the previous item's last plane is no longer being read
+        fetch(f0);
+        stash(f0 & 1);
+        __syncthreads();
+        float4 accA = make_float4(0.f, 0.f, 0.f, 0.f), accB = make_float4(0.f, 0.f, 0.f, 0.f);
+        T* dxo = dx + (((int64_t)n * g.di * g.hi + ih) * g.wi + iw) * g.x_ld + c0 + 4 * q;
+        const int64_t xplane = (int64_t)g.hi * g.wi * g.x_ld;
+        for (int f = f0; f <= f1; ++f) {
+            if (f < f1) fetch(f + 1);
+            // in-plane 4x4 taps of this lane's coarse (h, w): rows 2*ihl .. 2*ihl+3, columns 2*iwl .. 2*iwl+3 of the tile
+            const float4* base = pbuf[f & 1] + ((2 * ihl) * MFW + 2 * iwl) * MCQ + q;
+            float4 sf = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int bb = 0; bb < 4; ++bb) {
+                float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+                for (int cc = 0; cc < 4; ++cc) {
+                    const float4 gv = base[(bb * MFW + cc) * MCQ];
+                    r.x = fmaf(ww[cc], gv.x, r.x);
+                    r.y = fmaf(ww[cc], gv.y, r.y);
+                    r.z = fmaf(ww[cc], gv.z, r.z);
+                    r.w = fmaf(ww[cc], gv.w, r.w);
+                }
+                sf.x = fmaf(wh[bb], r.x, sf.x);
+                sf.y = fmaf(wh[bb], r.y, sf.y);
+                sf.z = fmaf(wh[bb], r.z, sf.z);
+                sf.w = fmaf(wh[bb], r.w, sf.w);
+            }
+            // D taps (uniform per workgroup): plane f is tap 1/2 of coarse i = f/2 and tap 0 of i+1 (f odd) / tap 3 of i-1 (f even)
+            const int i = f >> 1;
+            float wdi[4];
+            up2_axis_weights(i, g.di, wdi);
+            if (f & 1) {
+                if (i >= d0) { accA.x = fmaf(wdi[2], sf.x, accA.x); accA.y = fmaf(wdi[2], sf.y, accA.y);
+                               accA.z = fmaf(wdi[2], sf.z, accA.z); accA.w = fmaf(wdi[2], sf.w, accA.w); }
+                float wn[4];
+                up2_axis_weights(i + 1, g.di, wn);
+                if (i >= d0) { accB.x = wn[0] * sf.x; accB.y = wn[0] * sf.y; accB.z = wn[0] * sf.z; accB.w = wn[0] * sf.w; }
+                else { accA.x = wn[0] * sf.x; accA.y = wn[0] * sf.y; accA.z = wn[0] * sf.z; accA.w = wn[0] * sf.w; }   // f = 2*d0 - 1
+            } else {
+                if (i > d0) {
+                    // tap 3 closes coarse plane i-1
+                    float wp[4];
+                    up2_axis_weights(i - 1, g.di, wp);
+                    accA.x = fmaf(wp[3], sf.x, accA.x); accA.y = fmaf(wp[3], sf.y, accA.y);
+                    accA.z = fmaf(wp[3], sf.z, accA.z); accA.w = fmaf(wp[3], sf.w, accA.w);
+                    if (vok) stf4(dxo + (int64_t)(i - 1) * xplane, accA);
+                    accA = accB;
+                }
+                if (i < d1) { accA.x = fmaf(wdi[1], sf.x, accA.x); accA.y = fmaf(wdi[1], sf.y, accA.y);
+                              accA.z = fmaf(wdi[1], sf.z, accA.z); accA.w = fmaf(wdi[1], sf.w, accA.w); }
+            }
+            if (f < f1) stash((f + 1) & 1);
+            __syncthreads();
+        }
+        // the last coarse plane of the volume has no tap 3 (its fine plane 2*di does not exist): close it here
+        if (d1 == g.di && vok) stf4(dxo + (int64_t)(d1 - 1) * xplane, accA);
+    }
+}
+
 // ------------------------------------------------------------------ trilinear x2 forward, LDS-tiled
 // One lane = one coarse voxel x one channel quad: it reads its 3x3x3 coarse neighbourhood from an LDS halo tile and writes
 // the 2x2x2 fine voxels it owns (fine index 2i+e takes 0.75 of coarse i and 0.25 of coarse i-1 (e = 0) or i+1 (e = 1);
@@ -621,6 +757,19 @@ extern "C" int mri3d_upsample3d_bwd(const Mri3dUpGeom* g, const void* dy, void* 
     hipStream_t s = static_cast<hipStream_t>(stream);
     static const int no_fast = getenv("MRI3D_UP_GENERIC") ? atoi(getenv("MRI3D_UP_GENERIC")) : 0;   // tuning aid (A/B)
     if (!no_fast && up2x_fast_ok(*g) && aligned_vec4(g->dtype, dx, dy)) {
+        static const int march = getenv("MRI3D_UP_MARCH") ? atoi(getenv("MRI3D_UP_MARCH")) : 1;   // tuning aid (A/B)
+        if (march && g->c % 16 == 0) {
+            const int segsD = cdiv(g->di, MD), tilesH = cdiv(g->hi, MTH), tilesW = cdiv(g->wi, MTW), cpasses = g->c / 16;
+            const int64_t items = (int64_t)g->n * segsD * cpasses * tilesH * tilesW;
+            if (items <= 0x7ffffff0 && (int64_t)g->ho * g->wo * g->y_ld <= 0x7fffffff) {
+                const int grid = (int)std::min<int64_t>((items + 7) / 8 * 8, 256 * 3 * 8);
+                MRI3D_DISPATCH_DTYPE(g->dtype, T, {
+                    hipLaunchKernelGGL(upsample2x_bwd_march_kernel<T>, dim3(grid), dim3(256), 0, s, *g, (const T*)dy, (T*)dx,
+                                       segsD, tilesH, tilesW, cpasses, (int)items);
+                });
+                return check_launch("upsample3d_bwd(2x march)");
+            }
+        }
         // 16-channel passes pay off for fp32 (0.93 vs 1.25 ms on the c32 level); bf16 already reads 32-byte slices with 8
         // channels... measured 0.68 ms (CQ = 2) vs 0.96 ms (CQ = 4), so it keeps the 8-channel tile
         const bool wide = g->c % 16 == 0 && g->dtype == MRI3D_F32;
