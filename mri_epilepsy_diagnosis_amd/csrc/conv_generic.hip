@@ -430,6 +430,238 @@ conv_wgrad_small_kernel(Mri3dConvGeom g, const T* __restrict__ x, const T* __res
     }
 }
 
+// ------------------------------------------------------------------ first layer: 3x3x3, stride 1, pad 1, ONE input channel
+// unet.UNet / Modified3DUNet / CNN all start with Conv3d(1, 8|16, 3, padding=1) on the whole volume.  With Cin = 1 there is
+// no GEMM to speak of (K = 27): forward reads 4 B and writes 4*Co B per voxel, the weight gradient reads both, and 27*Co
+// FMAs per voxel keep the VALUs about as busy as HBM (~0.05 ms each per 2 x 160x192x160 volumes).  The generic forward
+// kernel needs 0.39 ms there and the CK = 1 MFMA weight gradient 0.47 ms; these two take 0.18 and 0.25 ms:
+//   forward: a 4 x 8 x (8*VPT) voxel tile of x (+halo) sits in LDS, a lane owns VPT consecutive voxels along W and all Co
+//            outputs; per (kd, kh) it reads its VPT+2 inputs once and reuses them for the 3 kw taps; weights are broadcast
+//            LDS reads.
+//   wgrad:   the same tile, but a workgroup owns ONE kd plane of the filter (9*Co accumulators per lane instead of 27*Co) and
+//            walks its share of the tiles; the three kd workgroups of a share sit next to each other on one XCD so that dy is
+//            fetched from HBM once.  Lanes are combined by wave shuffles + LDS in a fixed order, one partial per
+//            workgroup, then wgrad_reduce_kernel (deterministic).
+constexpr int C1D = 4, C1H = 8, C1WQ = 8;   // tile: 4 x 8 x (8*VPT) voxels, 256 lanes
+
+template <int CO> struct Cin1 { static constexpr int VPT = CO <= 8 ? 4 : 2; };
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+// sum over the 64 lanes of a wave, the same value in every lane: xor-1 / xor-2 inside quads, half-mirror and mirror inside
+// the 16-lane DPP rows, then the four row sums through readlane
+__device__ __forceinline__ float wave_sum_dpp(float v) {
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));    // quad_perm [1,0,3,2]
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));    // quad_perm [2,3,0,1]
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true));   // row_half_mirror
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xF, 0xF, true));   // row_mirror
+    const int vi = __builtin_bit_cast(int, v);
+    const float r0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(vi, 0));
+    const float r1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(vi, 16));
+    const float r2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(vi, 32));
+    const float r3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(vi, 48));
+    return (r0 + r1) + (r2 + r3);
+}
+
+// stage rows [dlo, dlo+ND) x (C1H+2) x (TW+2) of the zero-padded input around tile origin (d0, h0, w0) into LDS
+template <typename T, int TW, int ND>
+__device__ __forceinline__ void cin1_stage(float* xs, const T* __restrict__ xn, const Mri3dConvGeom& g, int dlo, int h0,
+                                           int w0, int tid) {
+    constexpr int PW = TW + 4, NE = ND * (C1H + 2) * (TW + 2);
+    for (int e = tid; e < NE; e += 256) {
+        const int fw = e % (TW + 2), r = e / (TW + 2);
+        const int fh = r % (C1H + 2), fd = r / (C1H + 2);
+        const int id = dlo + fd, ih = h0 - 1 + fh, iw = w0 - 1 + fw;
+        const bool ok = (unsigned)id < (unsigned)g.di && (unsigned)ih < (unsigned)g.hi && (unsigned)iw < (unsigned)g.wi;
+        const int cd = min(max(id, 0), g.di - 1), ch = min(max(ih, 0), g.hi - 1), cw = min(max(iw, 0), g.wi - 1);
+        const float v = ldf(xn + (((int64_t)cd * g.hi + ch) * g.wi + cw) * g.x_ld);
+        xs[(fd * (C1H + 2) + fh) * PW + fw] = ok ? v : 0.f;
+    }
+}
+
+template <typename T, int CO>
+__global__ void __launch_bounds__(256)
+conv_cin1_fwd_kernel(Mri3dConvGeom g, const T* __restrict__ x, const float* __restrict__ wp, const float* __restrict__ bias,
+                     T* __restrict__ y, int tilesD, int tilesH, int tilesW, int ntiles) {
+    // wp = repacked weights [tap][co].  They live in LDS and are re-read (broadcast) per (kd, kh) row through a pointer the
+    // compiler cannot see through: left to itself it hoists all 27*Co loop-invariant weights out of the tile loop
+    // (398 VGPRs+AGPRs, one wave per SIMD; as scalar loads: spilled to VGPR lanes, 722 v_readlane per tile).
+    constexpr int VPT = Cin1<CO>::VPT, TW = C1WQ * VPT, PW = TW + 4;
+    __shared__ __attribute__((aligned(16))) float xs[(C1D + 2) * (C1H + 2) * PW];
+    __shared__ __attribute__((aligned(16))) float wsh[27 * CO];
+    const int tid = threadIdx.x;
+    for (int e = tid; e < 27 * CO; e += 256) wsh[e] = wp[e];
+    const int wq = tid % C1WQ, hl = (tid / C1WQ) % C1H, dl = tid / (C1WQ * C1H);
+    float bv[CO];
+#pragma unroll
+    for (int c = 0; c < CO; ++c) bv[c] = bias ? bias[c] : 0.f;
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        int t = tile;
+        const int w0 = (t % tilesW) * TW;
+        t /= tilesW;
+        const int h0 = (t % tilesH) * C1H;
+        t /= tilesH;
+        const int d0 = (t % tilesD) * C1D;
+        const int n = t / tilesD;
+        __syncthreads();
+        cin1_stage<T, TW, C1D + 2>(xs, x + (int64_t)n * g.di * g.hi * g.wi * g.x_ld, g, d0 - 1, h0, w0, tid);
+        __syncthreads();
+        f32x2 acc[VPT][CO / 2];   // channel pairs: v_pk_fma_f32
+#pragma unroll
+        for (int v = 0; v < VPT; ++v)
+#pragma unroll
+            for (int c = 0; c < CO / 2; ++c) acc[v][c] = f32x2{bv[2 * c], bv[2 * c + 1]};
+#pragma unroll
+        for (int kd = 0; kd < 3; ++kd)
+#pragma unroll
+            for (int kh = 0; kh < 3; ++kh) {
+                const float* row = xs + ((dl + kd) * (C1H + 2) + hl + kh) * PW + wq * VPT;
+                float r[VPT + 2];
+#pragma unroll
+                for (int i = 0; i < VPT + 2; ++i) r[i] = row[i];
+                int woff = (kd * 3 + kh) * 3 * CO;
+                asm volatile("" : "+v"(woff));              // opaque offset: the weight reads stay inside the tile loop ...
+                __builtin_amdgcn_sched_barrier(0);          // ... and inside their (kd, kh) group
+                const float* wrow = wsh + woff;
+#pragma unroll
+                for (int kw = 0; kw < 3; ++kw) {
+                    const float* wt = wrow + kw * CO;
+#pragma unroll
+                    for (int c = 0; c < CO / 2; ++c) {
+                        const f32x2 wv = f32x2{wt[2 * c], wt[2 * c + 1]};
+#pragma unroll
+                        for (int v = 0; v < VPT; ++v)
+                            acc[v][c] = __builtin_elementwise_fma(f32x2{r[v + kw], r[v + kw]}, wv, acc[v][c]);
+                    }
+                }
+            }
+        // results are pinned here: otherwise the compiler sinks each voxel's 27*Co FMAs into its bounds-checked store below
+        // and keeps every weight and input row of the tile alive across all of them (256 VGPRs + AGPR traffic)
+#pragma unroll
+        for (int v = 0; v < VPT; ++v)
+#pragma unroll
+            for (int c = 0; c < CO / 2; ++c) asm volatile("" : "+v"(acc[v][c]));
+        const int od = d0 + dl, oh = h0 + hl;
+        if (od < g.dout && oh < g.ho) {
+            T* yo = y + ((((int64_t)n * g.dout + od) * g.ho + oh) * g.wo + w0 + wq * VPT) * g.y_ld;
+#pragma unroll
+            for (int v = 0; v < VPT; ++v)
+                if (w0 + wq * VPT + v < g.wo) {
+#pragma unroll
+                    for (int c = 0; c < CO; c += 4)
+                        stf4(yo + (int64_t)v * g.y_ld + c,
+                             make_float4(acc[v][c / 2].x, acc[v][c / 2].y, acc[v][c / 2 + 1].x, acc[v][c / 2 + 1].y));
+                }
+        }
+    }
+}
+
+template <typename T, int CO>
+__global__ void __launch_bounds__(256)
+conv_cin1_wgrad_kernel(Mri3dConvGeom g, const T* __restrict__ x, const T* __restrict__ dy, float* __restrict__ part,
+                       float* __restrict__ bias_part, int tilesD, int tilesH, int tilesW, int ntiles, int nshares) {
+    constexpr int VPT = Cin1<CO>::VPT, TW = C1WQ * VPT, PW = TW + 4, NA = 9 * CO + CO;
+    __shared__ __attribute__((aligned(16))) float xs[C1D * (C1H + 2) * PW];
+    __shared__ float red[4][NA];
+    const int tid = threadIdx.x;
+    // blockIdx -> (share, kd) with kd fastest inside one XCD's contiguous range (gridDim.x = 3 * nshares, a multiple of 8)
+    const int per_xcd = gridDim.x / 8;
+    const int logical = (blockIdx.x % 8) * per_xcd + blockIdx.x / 8;
+    const int kd = logical % 3, share = logical / 3;
+    const int wq = tid % C1WQ, hl = (tid / C1WQ) % C1H, dl = tid / (C1WQ * C1H);
+    f32x2 acc[3][3][CO / 2];   // channel pairs: v_pk_fma_f32
+    float bsum[CO];
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int b = 0; b < 3; ++b)
+#pragma unroll
+            for (int c = 0; c < CO / 2; ++c) acc[a][b][c] = f32x2{0.f, 0.f};
+#pragma unroll
+    for (int c = 0; c < CO; ++c) bsum[c] = 0.f;
+    for (int tile = share; tile < ntiles; tile += nshares) {
+        int t = tile;
+        const int w0 = (t % tilesW) * TW;
+        t /= tilesW;
+        const int h0 = (t % tilesH) * C1H;
+        t /= tilesH;
+        const int d0 = (t % tilesD) * C1D;
+        const int n = t / tilesD;
+        __syncthreads();
+        cin1_stage<T, TW, C1D>(xs, x + (int64_t)n * g.di * g.hi * g.wi * g.x_ld, g, d0 + kd - 1, h0, w0, tid);
+        // this lane's VPT output voxels of dy (zero outside the volume)
+        const int od = d0 + dl, oh = h0 + hl;
+        f32x2 gy[VPT][CO / 2];
+#pragma unroll
+        for (int v = 0; v < VPT; ++v) {
+            const int ow = w0 + wq * VPT + v;
+            const bool ok = od < g.dout && oh < g.ho && ow < g.wo;
+            const T* dp = dy + ((((int64_t)n * g.dout + min(od, g.dout - 1)) * g.ho + min(oh, g.ho - 1)) * g.wo +
+                                min(ow, g.wo - 1)) * g.y_ld;
+#pragma unroll
+            for (int c = 0; c < CO; c += 4) {
+                const float4 q = ldf4(dp + c);
+                gy[v][c / 2] = f32x2{ok ? q.x : 0.f, ok ? q.y : 0.f};
+                gy[v][c / 2 + 1] = f32x2{ok ? q.z : 0.f, ok ? q.w : 0.f};
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh) {
+            const float* row = xs + (dl * (C1H + 2) + hl + kh) * PW + wq * VPT;
+            float r[VPT + 2];
+#pragma unroll
+            for (int i = 0; i < VPT + 2; ++i) r[i] = row[i];
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw)
+#pragma unroll
+                for (int v = 0; v < VPT; ++v)
+#pragma unroll
+                    for (int c = 0; c < CO / 2; ++c)
+                        acc[kh][kw][c] = __builtin_elementwise_fma(f32x2{r[v + kw], r[v + kw]}, gy[v][c], acc[kh][kw][c]);
+        }
+        if (kd == 1) {
+#pragma unroll
+            for (int v = 0; v < VPT; ++v)
+#pragma unroll
+                for (int c = 0; c < CO / 2; ++c) { bsum[2 * c] += gy[v][c].x; bsum[2 * c + 1] += gy[v][c].y; }
+        }
+    }
+    // lanes -> wave with DPP adds inside the 16-lane rows + the four row sums (fixed order), waves -> workgroup through LDS
+    // (ds_bpermute shuffles here cost 480 LDS round trips per workgroup, 40 % of its run time)
+    const int lane = tid & 63, wave = tid >> 6;
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int b = 0; b < 3; ++b)
+#pragma unroll
+            for (int c = 0; c < CO; ++c) {
+                const float vsum = wave_sum_dpp((c & 1) ? acc[a][b][c / 2].y : acc[a][b][c / 2].x);
+                if (lane == 0) red[wave][(a * 3 + b) * CO + c] = vsum;
+            }
+#pragma unroll
+    for (int c = 0; c < CO; ++c) {
+        const float vsum = wave_sum_dpp(bsum[c]);
+        if (lane == 0) red[wave][9 * CO + c] = vsum;
+    }
+    __syncthreads();
+    if (tid < 9 * CO) {
+        const float t4 = (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]);
+        part[((size_t)share * 27 + kd * 9 + tid / CO) * CO + tid % CO] = t4;   // part[share][tap][ci = 0][co]
+    } else if (tid < NA && kd == 1 && bias_part) {
+        const int c = tid - 9 * CO;
+        bias_part[(size_t)share * CO + c] = (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]);
+    }
+}
+
+static const int g_cin1_off = getenv("MRI3D_CIN1_OFF") ? atoi(getenv("MRI3D_CIN1_OFF")) : 0;   // tuning aid (A/B)
+constexpr int kCin1Shares = 256;   // 3 * 256 = 768 workgroups = 3 per CU
+
+static bool cin1_ok(const Mri3dConvGeom& g) {
+    return !g_cin1_off && g.ci == 1 && (g.co == 8 || g.co == 16) && g.kd == 3 && g.kh == 3 && g.kw == 3 && g.sd == 1 &&
+           g.sh == 1 && g.sw == 1 && g.dd == 1 && g.dh == 1 && g.dw == 1 && g.pd == 1 && g.ph == 1 && g.pw == 1 &&
+           g.y_ld % 4 == 0 && (int64_t)g.n * cdiv(g.dout, C1D) * cdiv(g.ho, C1H) * cdiv(g.wo, C1WQ * 2) < 0x7fffffffLL;
+}
+
 static bool wgrad_small_ok(const Mri3dConvGeom& g) {
     const int taps = g.kd * g.kh * g.kw;
     return taps <= kSmTaps && g.ci <= 64 && g.co <= 64 && (int64_t)g.dout * g.ho * g.wo < 0x7fffffffLL;
@@ -498,6 +730,7 @@ size_t conv_generic_workspace_bytes(const Mri3dConvGeom& g, int pass) {
     }
     WgradPlan p = wgrad_plan(g);
     size_t a = (p.part_floats + p.bias_floats) * sizeof(float);
+    if (cin1_ok(g)) a = std::max(a, (size_t)kCin1Shares * (27 + 1) * g.co * sizeof(float));
     if (wgrad_small_ok(g)) {
         WgradSmallPlan q = wgrad_small_plan(g);
         a = std::max(a, (q.part_floats + q.bias_floats) * sizeof(float));
@@ -521,6 +754,25 @@ static void launch_fwd(const Mri3dConvGeom& g, const void* x, const float* wp, c
 
 int conv_generic_fwd(const Mri3dConvGeom& g, const void* x, const float* w, const float* bias, void* y, void* ws,
                      size_t ws_bytes, hipStream_t s) {
+    if (cin1_ok(g) && aligned_vec4(g.dtype, y)) {
+        const size_t need1 = (size_t)27 * g.co * sizeof(float);
+        MRI3D_REQUIRE(ws != nullptr && ws_bytes >= need1, MRI3D_EWORKSPACE, "conv3d_fwd: workspace %zu < %zu", ws_bytes, need1);
+        float* wp = static_cast<float*>(ws);
+        hipLaunchKernelGGL(repack_w_fwd_kernel, dim3(1), dim3(256), 0, s, w, wp, g.co, 1, 27, g.co);
+        const int vpt = g.co <= 8 ? 4 : 2;
+        const int tilesD = cdiv(g.dout, C1D), tilesH = cdiv(g.ho, C1H), tilesW = cdiv(g.wo, C1WQ * vpt);
+        const int ntiles = g.n * tilesD * tilesH * tilesW;
+        const int grid = std::min(ntiles, 256 * 8);
+        MRI3D_DISPATCH_DTYPE(g.dtype, T, {
+            if (g.co == 8)
+                hipLaunchKernelGGL((conv_cin1_fwd_kernel<T, 8>), dim3(grid), dim3(256), 0, s, g, (const T*)x, wp, bias, (T*)y,
+                                   tilesD, tilesH, tilesW, ntiles);
+            else
+                hipLaunchKernelGGL((conv_cin1_fwd_kernel<T, 16>), dim3(grid), dim3(256), 0, s, g, (const T*)x, wp, bias, (T*)y,
+                                   tilesD, tilesH, tilesW, ntiles);
+        });
+        return check_launch("conv3d_fwd(cin1)");
+    }
     const int taps = g.kd * g.kh * g.kw;
     const int TL = pick_tile(g.co);
     const int CoP = cdiv(g.co, TL) * TL;
@@ -576,6 +828,27 @@ int conv_generic_dgrad(const Mri3dConvGeom& g, const void* dy, const float* w, c
 
 int conv_generic_wgrad(const Mri3dConvGeom& g, const void* x, const void* dy, float* dw, float* dbias, void* ws,
                        size_t ws_bytes, hipStream_t s) {
+    if (cin1_ok(g) && aligned_vec4(g.dtype, dy)) {
+        const size_t need = (size_t)kCin1Shares * (27 + 1) * g.co * sizeof(float);
+        MRI3D_REQUIRE(ws != nullptr && ws_bytes >= need, MRI3D_EWORKSPACE, "conv3d_wgrad: workspace %zu < %zu", ws_bytes, need);
+        const int vpt = g.co <= 8 ? 4 : 2;
+        const int tilesD = cdiv(g.dout, C1D), tilesH = cdiv(g.ho, C1H), tilesW = cdiv(g.wo, C1WQ * vpt);
+        const int ntiles = g.n * tilesD * tilesH * tilesW;
+        float* part = static_cast<float*>(ws);
+        float* bias_part = dbias ? part + (size_t)kCin1Shares * 27 * g.co : nullptr;
+        // every (share, kd) workgroup writes its slots, also when its share of the tiles is empty (zeros)
+        MRI3D_DISPATCH_DTYPE(g.dtype, T, {
+            if (g.co == 8)
+                hipLaunchKernelGGL((conv_cin1_wgrad_kernel<T, 8>), dim3(3 * kCin1Shares), dim3(256), 0, s, g, (const T*)x,
+                                   (const T*)dy, part, bias_part, tilesD, tilesH, tilesW, ntiles, kCin1Shares);
+            else
+                hipLaunchKernelGGL((conv_cin1_wgrad_kernel<T, 16>), dim3(3 * kCin1Shares), dim3(256), 0, s, g, (const T*)x,
+                                   (const T*)dy, part, bias_part, tilesD, tilesH, tilesW, ntiles, kCin1Shares);
+        });
+        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(cdiv(27 * g.co + g.co, 8)), dim3(256), 0, s, part, bias_part, dw, dbias,
+                           kCin1Shares, 27, 1, g.co, 1, g.co);
+        return check_launch("conv3d_wgrad(cin1)");
+    }
     if (wgrad_small_ok(g)) {
         WgradSmallPlan q = wgrad_small_plan(g);
         const size_t need = (q.part_floats + q.bias_floats) * sizeof(float);

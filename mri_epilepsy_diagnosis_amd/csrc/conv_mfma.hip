@@ -1476,8 +1476,13 @@ static bool mfma_wgrad_plan(const Mri3dConvGeom& g, MfmaWgradPlan& p) {
     if (p.v2 == 3) p.CK = 16;
     else if (g.ci % 16 == 0) p.CK = 16;
     else if (g.ci % 8 == 0) p.CK = 8;
-    else if (g.ci == 1) p.CK = 1;
-    else return false;
+    else if (g.ci == 1) {
+        // Conv3d(1, 8|16, 3): the direct first-layer kernel of conv_generic.hip (conv_cin1_wgrad_kernel) takes these
+        static const int cin1_mfma = getenv("MRI3D_CIN1_MFMA") ? atoi(getenv("MRI3D_CIN1_MFMA")) : 0;   // tuning aid (A/B)
+        // (Co = 8: 0.25 vs 0.47 ms on 2 x 160x192x160; Co = 16 stays here: 0.22 vs 0.24 ms on 16 x 64^3)
+        if (!cin1_mfma && g.co == 8 && g.y_ld % 4 == 0) return false;
+        p.CK = 1;
+    } else return false;
     if (p.CK >= 4 && g.x_ld % 4 != 0) return false;
     p.CIT = cdiv(g.ci, p.CK);
     p.COB = cdiv(g.co, 16);

@@ -70,3 +70,45 @@ def test_conv3x3x3_random_geometry(case, dtype):
     close(xg.grad, dxr, tol_act, "dx")
     close(wg.grad, dwr, tol_par, "dw")
     close(bg.grad, dbr, tol_par, "db")
+
+
+FIRST = [(2, 8, 9, 13, 37, True, 0), (1, 16, 8, 16, 32, False, 0), (1, 8, 4, 8, 32, False, 8), (3, 16, 5, 7, 19, True, 0),
+         (1, 8, 1, 1, 1, True, 0), (1, 8, 17, 9, 70, True, 8), (2, 16, 6, 20, 33, True, 16), (1, 8, 12, 24, 64, False, 0)]
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
+@pytest.mark.parametrize("case", FIRST, ids=lambda c: "n%d_1-%d_%dx%dx%d_b%d_p%d" % c)
+def test_first_layer_conv_one_input_channel(case, dtype):
+    """Conv3d(1, 8|16, 3, padding=1): the direct first-layer kernels (conv_cin1_{fwd,wgrad}_kernel), ragged tiles, outputs
+    written into / gradients read from a pitched channel slice."""
+    nb, co, d, h, w, bias, pad_out = case
+    g = torch.Generator().manual_seed(co * 1000 + d * 100 + h * 10 + w)
+    x = torch.randn(nb, 1, d, h, w, generator=g)
+    wt = torch.randn(co, 1, 3, 3, 3, generator=g) * 0.2
+    b = torch.randn(co, generator=g) if bias else None
+    dy = torch.randn(nb, co, d, h, w, generator=g)
+    if dtype == torch.bfloat16:
+        x, dy = x.to(dtype).float(), dy.to(dtype).float()
+    xg = x.cuda().to(dtype).requires_grad_(True)
+    wg = wt.cuda().requires_grad_(True)
+    bg = b.cuda().requires_grad_(True) if bias else None
+    yg = ops.conv3d(xg, wg, bg, padding=1)
+    dybuf = torch.zeros(nb, co + pad_out, d, h, w, device="cuda", dtype=dtype).contiguous(memory_format=torch.channels_last_3d)
+    dybuf[:, pad_out:] = dy.cuda().to(dtype)
+    yg.backward(dybuf[:, pad_out:])
+    x64, w64 = x.double().requires_grad_(True), wt.double().requires_grad_(True)
+    b64 = b.double().requires_grad_(True) if bias else None
+    r = F.conv3d(x64, w64, b64, padding=1)
+    r.backward(dy.double())
+    tol_act = 2e-5 if dtype == torch.float32 else 1.2e-2       # bf16: y / dx are rounded to bf16 on store
+    tol_par = 2e-5 if dtype == torch.float32 else 2e-5         # parameter gradients accumulate in fp32 from exact inputs
+
+    def close(a, ref, tol, what):
+        err = (a.detach().double().cpu() - ref).abs().max().item()
+        assert err <= tol * (ref.abs().max().item() + 1e-6), "%s: %.3e vs scale %.3e" % (what, err, ref.abs().max().item())
+
+    close(yg, r.detach(), tol_act, "y")
+    close(xg.grad, x64.grad, tol_act, "dx")
+    close(wg.grad, w64.grad, tol_par, "dw")
+    if bias:
+        close(bg.grad, b64.grad, tol_par, "db")
