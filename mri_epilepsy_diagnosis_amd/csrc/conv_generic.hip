@@ -9,6 +9,21 @@
 
 namespace mri3d {
 
+// sum over the 64 lanes of a wave, the same value in every lane: xor-1 / xor-2 inside quads, half-mirror and mirror inside
+// the 16-lane DPP rows, then the four row sums through readlane
+__device__ __forceinline__ float wave_sum_dpp(float v) {
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));    // quad_perm [1,0,3,2]
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));    // quad_perm [2,3,0,1]
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true));   // row_half_mirror
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xF, 0xF, true));   // row_mirror
+    const int vi = __builtin_bit_cast(int, v);
+    const float r0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(vi, 0));
+    const float r1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(vi, 16));
+    const float r2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(vi, 32));
+    const float r3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(vi, 48));
+    return (r0 + r1) + (r2 + r3);
+}
+
 // ------------------------------------------------------------------ weight repack
 // torch (Co, Ci, kd, kh, kw)  ->  fwd  Wf[tap][ci][coP]   (coP = Co rounded up to the cout tile)
 //                             ->  dgrad Wd[tap][co][ciP]
@@ -430,6 +445,85 @@ conv_wgrad_small_kernel(Mri3dConvGeom g, const T* __restrict__ x, const T* __res
     }
 }
 
+// ------------------------------------------------------------------ weight gradient, few taps, ONE output channel
+// The decoder's last separable convs end in a single channel (8 -> 1 and 1 -> 1 with (3,1,1)/(1,3,1)/(1,1,3) kernels at full
+// resolution, AE_model.py:110-160).  In the kernel above a lane owns one input channel and reads it 4 bytes at a time while 7 of
+// its 8 output-channel slots stay empty (1.32 ms for 8 -> 1 on 4 x 160x192x160, 536 GB/s).  Here a lane owns a VOXEL: one dy
+// value, CI input channels per tap as 16-byte loads, taps x CI accumulators; lanes are combined with DPP wave sums.
+template <typename T, int CI>
+__global__ void __launch_bounds__(256)
+conv_wgrad_co1_kernel(Mri3dConvGeom g, const T* __restrict__ x, const T* __restrict__ dy, float* __restrict__ part,
+                      float* __restrict__ bias_part) {
+    __shared__ float red[4][kSmTaps * CI + 1];
+    const int taps = g.kd * g.kh * g.kw;
+    const int tid = threadIdx.x;
+    float acc[kSmTaps][CI], bsum = 0.f;
+#pragma unroll
+    for (int t = 0; t < kSmTaps; ++t)
+#pragma unroll
+        for (int c = 0; c < CI; ++c) acc[t][c] = 0.f;
+    const int64_t per_n = (int64_t)g.dout * g.ho * g.wo;
+    const int64_t nvox = (int64_t)g.n * per_n;
+    for (int64_t v = (int64_t)blockIdx.x * 256 + tid; v < nvox; v += (int64_t)gridDim.x * 256) {
+        const int n = (int)(v / per_n);
+        unsigned r = (unsigned)(v - (int64_t)n * per_n);
+        const int ow = r % g.wo;
+        r /= g.wo;
+        const int oh = r % g.ho, od = r / g.ho;
+        const float gv = ldf(dy + v * g.y_ld);
+        bsum += gv;
+        const T* xn = x + (int64_t)n * g.di * g.hi * g.wi * g.x_ld;
+#pragma unroll
+        for (int t = 0; t < kSmTaps; ++t) {
+            if (t < taps) {
+                const int kw = t % g.kw, kh = (t / g.kw) % g.kh, kd = t / (g.kw * g.kh);
+                const int id = od * g.sd - g.pd + kd * g.dd, ih = oh * g.sh - g.ph + kh * g.dh, iw = ow * g.sw - g.pw + kw * g.dw;
+                const bool ok = (unsigned)id < (unsigned)g.di && (unsigned)ih < (unsigned)g.hi && (unsigned)iw < (unsigned)g.wi;
+                const T* xp = xn + (((int64_t)min(max(id, 0), g.di - 1) * g.hi + min(max(ih, 0), g.hi - 1)) * g.wi +
+                                    min(max(iw, 0), g.wi - 1)) * g.x_ld;
+                const float gm = ok ? gv : 0.f;
+                if constexpr (CI == 1) {
+                    acc[t][0] = fmaf(ldf(xp), gm, acc[t][0]);
+                } else {
+#pragma unroll
+                    for (int c = 0; c < CI; c += 4) {
+                        const float4 q = ldf4(xp + c);
+                        acc[t][c] = fmaf(q.x, gm, acc[t][c]);
+                        acc[t][c + 1] = fmaf(q.y, gm, acc[t][c + 1]);
+                        acc[t][c + 2] = fmaf(q.z, gm, acc[t][c + 2]);
+                        acc[t][c + 3] = fmaf(q.w, gm, acc[t][c + 3]);
+                    }
+                }
+            }
+        }
+    }
+    const int lane = tid & 63, wave = tid >> 6;
+#pragma unroll
+    for (int t = 0; t < kSmTaps; ++t)
+#pragma unroll
+        for (int c = 0; c < CI; ++c) {
+            const float vsum = wave_sum_dpp(acc[t][c]);
+            if (lane == 0) red[wave][t * CI + c] = vsum;
+        }
+    {
+        const float vsum = wave_sum_dpp(bsum);
+        if (lane == 0) red[wave][kSmTaps * CI] = vsum;
+    }
+    __syncthreads();
+    if (tid < taps * CI)   // part[blk][tap][ci][co = 0]
+        part[(size_t)blockIdx.x * taps * CI + tid] = (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]);
+    else if (tid == kSmTaps * CI && bias_part)
+        bias_part[blockIdx.x] = (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]);
+}
+
+constexpr int kCo1Blocks = 1024;
+
+static bool wgrad_co1_ok(const Mri3dConvGeom& g) {
+    static const int off = getenv("MRI3D_CO1_OFF") ? atoi(getenv("MRI3D_CO1_OFF")) : 0;   // tuning aid (A/B)
+    return !off && g.co == 1 && g.kd * g.kh * g.kw <= kSmTaps && (g.ci == 1 || ((g.ci == 4 || g.ci == 8 || g.ci == 16) && g.x_ld % 4 == 0)) &&
+           (int64_t)g.dout * g.ho * g.wo < 0x7fffffffLL;
+}
+
 // ------------------------------------------------------------------ first layer: 3x3x3, stride 1, pad 1, ONE input channel
 // unet.UNet / Modified3DUNet / CNN all start with Conv3d(1, 8|16, 3, padding=1) on the whole volume.  With Cin = 1 there is
 // no GEMM to speak of (K = 27): forward reads 4 B and writes 4*Co B per voxel, the weight gradient reads both, and 27*Co
@@ -447,20 +541,7 @@ constexpr int C1D = 4, C1H = 8, C1WQ = 8;   // tile: 4 x 8 x (8*VPT) voxels, 256
 template <int CO> struct Cin1 { static constexpr int VPT = CO <= 8 ? 4 : 2; };
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
-// sum over the 64 lanes of a wave, the same value in every lane: xor-1 / xor-2 inside quads, half-mirror and mirror inside
-// the 16-lane DPP rows, then the four row sums through readlane
-__device__ __forceinline__ float wave_sum_dpp(float v) {
-    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));    // quad_perm [1,0,3,2]
-    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));    // quad_perm [2,3,0,1]
-    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true));   // row_half_mirror
-    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xF, 0xF, true));   // row_mirror
-    const int vi = __builtin_bit_cast(int, v);
-    const float r0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(vi, 0));
-    const float r1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(vi, 16));
-    const float r2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(vi, 32));
-    const float r3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(vi, 48));
-    return (r0 + r1) + (r2 + r3);
-}
+
 
 // stage rows [dlo, dlo+ND) x (C1H+2) x (TW+2) of the zero-padded input around tile origin (d0, h0, w0) into LDS
 template <typename T, int TW, int ND>
@@ -653,6 +734,145 @@ conv_cin1_wgrad_kernel(Mri3dConvGeom g, const T* __restrict__ x, const T* __rest
     }
 }
 
+// ------------------------------------------------------------------ 3x3x3 stencil: ONE input and ONE output channel
+// The autoencoder's last layer `vox = Conv3d(1, 1, 3, padding=1)` (AE_model.py:160) on the whole reconstructed volume: 8 bytes of
+// traffic and 27 FMAs per voxel.  The generic kernels spend 0.55 / 0.82 / 0.72 ms (fwd / dgrad / wgrad, 4 x 160x192x160) on it,
+// 200-300 GB/s.  Same LDS tile as the first-layer kernels above; the 27 weights sit in SGPRs; dgrad = the same stencil with the
+// taps reversed, applied to dy; wgrad keeps 27 accumulators per lane.
+template <typename T>
+__global__ void __launch_bounds__(256)
+conv_c1c1_stencil_kernel(Mri3dConvGeom g, const T* __restrict__ x, int x_ld, const float* __restrict__ w, const float* __restrict__ bias,
+                         int flip, T* __restrict__ y, int y_ld, int tilesD, int tilesH, int tilesW, int ntiles) {
+    constexpr int VPT = 4, TW = C1WQ * VPT, PW = TW + 4;
+    __shared__ __attribute__((aligned(16))) float xs[(C1D + 2) * (C1H + 2) * PW];
+    const int tid = threadIdx.x;
+    const int wq = tid % C1WQ, hl = (tid / C1WQ) % C1H, dl = tid / (C1WQ * C1H);
+    float wt[27];
+#pragma unroll
+    for (int t = 0; t < 27; ++t) wt[t] = w[flip ? 26 - t : t];   // uniform -> scalar registers
+    const float b0 = bias ? bias[0] : 0.f;
+    Mri3dConvGeom gs = g;
+    gs.x_ld = x_ld;   // cin1_stage reads its source pitch from the geometry
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        int t = tile;
+        const int w0 = (t % tilesW) * TW;
+        t /= tilesW;
+        const int h0 = (t % tilesH) * C1H;
+        t /= tilesH;
+        const int d0 = (t % tilesD) * C1D;
+        const int n = t / tilesD;
+        __syncthreads();
+        cin1_stage<T, TW, C1D + 2>(xs, x + (int64_t)n * g.di * g.hi * g.wi * x_ld, gs, d0 - 1, h0, w0, tid);
+        __syncthreads();
+        float acc[VPT];
+#pragma unroll
+        for (int v = 0; v < VPT; ++v) acc[v] = b0;
+#pragma unroll
+        for (int kd = 0; kd < 3; ++kd)
+#pragma unroll
+            for (int kh = 0; kh < 3; ++kh) {
+                const float* row = xs + ((dl + kd) * (C1H + 2) + hl + kh) * PW + wq * VPT;
+                float r[VPT + 2];
+#pragma unroll
+                for (int i = 0; i < VPT + 2; ++i) r[i] = row[i];
+#pragma unroll
+                for (int kw = 0; kw < 3; ++kw)
+#pragma unroll
+                    for (int v = 0; v < VPT; ++v) acc[v] = fmaf(r[v + kw], wt[(kd * 3 + kh) * 3 + kw], acc[v]);
+            }
+#pragma unroll
+        for (int v = 0; v < VPT; ++v) asm volatile("" : "+v"(acc[v]));
+        const int od = d0 + dl, oh = h0 + hl;
+        if (od < g.di && oh < g.hi) {
+            T* yo = y + ((((int64_t)n * g.di + od) * g.hi + oh) * g.wi + w0 + wq * VPT) * y_ld;
+#pragma unroll
+            for (int v = 0; v < VPT; ++v)
+                if (w0 + wq * VPT + v < g.wi) stf(yo + (int64_t)v * y_ld, acc[v]);
+        }
+    }
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256)
+conv_c1c1_wgrad_kernel(Mri3dConvGeom g, const T* __restrict__ x, const T* __restrict__ dy, float* __restrict__ part,
+                       float* __restrict__ bias_part, int tilesD, int tilesH, int tilesW, int ntiles) {
+    constexpr int VPT = 4, TW = C1WQ * VPT, PW = TW + 4;
+    __shared__ __attribute__((aligned(16))) float xs[(C1D + 2) * (C1H + 2) * PW];
+    __shared__ float red[4][28];
+    const int tid = threadIdx.x;
+    const int wq = tid % C1WQ, hl = (tid / C1WQ) % C1H, dl = tid / (C1WQ * C1H);
+    float acc[27], bsum = 0.f;
+#pragma unroll
+    for (int t = 0; t < 27; ++t) acc[t] = 0.f;
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        int t = tile;
+        const int w0 = (t % tilesW) * TW;
+        t /= tilesW;
+        const int h0 = (t % tilesH) * C1H;
+        t /= tilesH;
+        const int d0 = (t % tilesD) * C1D;
+        const int n = t / tilesD;
+        __syncthreads();
+        cin1_stage<T, TW, C1D + 2>(xs, x + (int64_t)n * g.di * g.hi * g.wi * g.x_ld, g, d0 - 1, h0, w0, tid);
+        const int od = d0 + dl, oh = h0 + hl;
+        float gy[VPT];
+#pragma unroll
+        for (int v = 0; v < VPT; ++v) {
+            const int ow = w0 + wq * VPT + v;
+            const bool ok = od < g.dout && oh < g.ho && ow < g.wo;
+            const float q = ldf(dy + ((((int64_t)n * g.dout + min(od, g.dout - 1)) * g.ho + min(oh, g.ho - 1)) * g.wo +
+                                      min(ow, g.wo - 1)) * g.y_ld);
+            gy[v] = ok ? q : 0.f;
+            bsum += gy[v];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int kd = 0; kd < 3; ++kd)
+#pragma unroll
+            for (int kh = 0; kh < 3; ++kh) {
+                const float* row = xs + ((dl + kd) * (C1H + 2) + hl + kh) * PW + wq * VPT;
+                float r[VPT + 2];
+#pragma unroll
+                for (int i = 0; i < VPT + 2; ++i) r[i] = row[i];
+#pragma unroll
+                for (int kw = 0; kw < 3; ++kw)
+#pragma unroll
+                    for (int v = 0; v < VPT; ++v) acc[(kd * 3 + kh) * 3 + kw] = fmaf(r[v + kw], gy[v], acc[(kd * 3 + kh) * 3 + kw]);
+            }
+    }
+    const int lane = tid & 63, wave = tid >> 6;
+#pragma unroll
+    for (int t = 0; t < 27; ++t) {
+        const float vsum = wave_sum_dpp(acc[t]);
+        if (lane == 0) red[wave][t] = vsum;
+    }
+    {
+        const float vsum = wave_sum_dpp(bsum);
+        if (lane == 0) red[wave][27] = vsum;
+    }
+    __syncthreads();
+    if (tid < 27) part[(size_t)blockIdx.x * 27 + tid] = (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]);
+    else if (tid == 27 && bias_part) bias_part[blockIdx.x] = (red[0][27] + red[1][27]) + (red[2][27] + red[3][27]);
+}
+
+constexpr int kC1C1Blocks = 1024;
+
+static bool c1c1_ok(const Mri3dConvGeom& g) {
+    static const int off = getenv("MRI3D_C1C1_OFF") ? atoi(getenv("MRI3D_C1C1_OFF")) : 0;   // tuning aid (A/B)
+    return !off && g.ci == 1 && g.co == 1 && g.kd == 3 && g.kh == 3 && g.kw == 3 && g.sd == 1 && g.sh == 1 && g.sw == 1 &&
+           g.dd == 1 && g.dh == 1 && g.dw == 1 && g.pd == 1 && g.ph == 1 && g.pw == 1 &&
+           (int64_t)g.n * cdiv(g.dout, C1D) * cdiv(g.ho, C1H) * cdiv(g.wo, C1WQ * 4) < 0x7fffffffLL;
+}
+
+template <typename T>
+static void launch_c1c1_stencil(const Mri3dConvGeom& g, const T* src, int src_ld, const float* w, const float* bias, int flip,
+                                T* dst, int dst_ld, hipStream_t s) {
+    const int tilesD = cdiv(g.di, C1D), tilesH = cdiv(g.hi, C1H), tilesW = cdiv(g.wi, C1WQ * 4);
+    const int ntiles = g.n * tilesD * tilesH * tilesW;
+    hipLaunchKernelGGL(conv_c1c1_stencil_kernel<T>, dim3(std::min(ntiles, 256 * 8)), dim3(256), 0, s, g, src, src_ld, w, bias, flip,
+                       dst, dst_ld, tilesD, tilesH, tilesW, ntiles);
+}
+
 static const int g_cin1_off = getenv("MRI3D_CIN1_OFF") ? atoi(getenv("MRI3D_CIN1_OFF")) : 0;   // tuning aid (A/B)
 constexpr int kCin1Shares = 256;   // 3 * 256 = 768 workgroups = 3 per CU
 
@@ -731,6 +951,8 @@ size_t conv_generic_workspace_bytes(const Mri3dConvGeom& g, int pass) {
     WgradPlan p = wgrad_plan(g);
     size_t a = (p.part_floats + p.bias_floats) * sizeof(float);
     if (cin1_ok(g)) a = std::max(a, (size_t)kCin1Shares * (27 + 1) * g.co * sizeof(float));
+    if (c1c1_ok(g)) a = std::max(a, (size_t)kC1C1Blocks * 28 * sizeof(float));
+    if (wgrad_co1_ok(g)) a = std::max(a, (size_t)kCo1Blocks * (kSmTaps * 16 + 1) * sizeof(float));
     if (wgrad_small_ok(g)) {
         WgradSmallPlan q = wgrad_small_plan(g);
         a = std::max(a, (q.part_floats + q.bias_floats) * sizeof(float));
@@ -754,6 +976,10 @@ static void launch_fwd(const Mri3dConvGeom& g, const void* x, const float* wp, c
 
 int conv_generic_fwd(const Mri3dConvGeom& g, const void* x, const float* w, const float* bias, void* y, void* ws,
                      size_t ws_bytes, hipStream_t s) {
+    if (c1c1_ok(g)) {
+        MRI3D_DISPATCH_DTYPE(g.dtype, T, { launch_c1c1_stencil<T>(g, (const T*)x, g.x_ld, w, bias, 0, (T*)y, g.y_ld, s); });
+        return check_launch("conv3d_fwd(1->1 stencil)");
+    }
     if (cin1_ok(g) && aligned_vec4(g.dtype, y)) {
         const size_t need1 = (size_t)27 * g.co * sizeof(float);
         MRI3D_REQUIRE(ws != nullptr && ws_bytes >= need1, MRI3D_EWORKSPACE, "conv3d_fwd: workspace %zu < %zu", ws_bytes, need1);
@@ -807,6 +1033,11 @@ static void launch_dgrad(const Mri3dConvGeom& g, const void* dy, const float* wp
 
 int conv_generic_dgrad(const Mri3dConvGeom& g, const void* dy, const float* w, const float* bias, void* dx, void* ws,
                        size_t ws_bytes, hipStream_t s) {
+    if (c1c1_ok(g)) {
+        // dx = the same stencil with reversed taps, applied to dy (pad 1, stride 1: the transposed conv is a conv)
+        MRI3D_DISPATCH_DTYPE(g.dtype, T, { launch_c1c1_stencil<T>(g, (const T*)dy, g.y_ld, w, bias, 1, (T*)dx, g.x_ld, s); });
+        return check_launch("conv3d_dgrad(1->1 stencil)");
+    }
     const int taps = g.kd * g.kh * g.kw;
     const int TL = pick_tile(g.ci);
     const int CiP = cdiv(g.ci, TL) * TL;
@@ -828,6 +1059,21 @@ int conv_generic_dgrad(const Mri3dConvGeom& g, const void* dy, const float* w, c
 
 int conv_generic_wgrad(const Mri3dConvGeom& g, const void* x, const void* dy, float* dw, float* dbias, void* ws,
                        size_t ws_bytes, hipStream_t s) {
+    if (c1c1_ok(g)) {
+        const size_t need = (size_t)kC1C1Blocks * 28 * sizeof(float);
+        MRI3D_REQUIRE(ws != nullptr && ws_bytes >= need, MRI3D_EWORKSPACE, "conv3d_wgrad: workspace %zu < %zu", ws_bytes, need);
+        const int tilesD = cdiv(g.dout, C1D), tilesH = cdiv(g.ho, C1H), tilesW = cdiv(g.wo, C1WQ * 4);
+        const int ntiles = g.n * tilesD * tilesH * tilesW;
+        const int nb = std::min(ntiles, kC1C1Blocks);
+        float* part = static_cast<float*>(ws);
+        float* bias_part = dbias ? part + (size_t)kC1C1Blocks * 27 : nullptr;
+        MRI3D_DISPATCH_DTYPE(g.dtype, T, {
+            hipLaunchKernelGGL(conv_c1c1_wgrad_kernel<T>, dim3(nb), dim3(256), 0, s, g, (const T*)x, (const T*)dy, part, bias_part,
+                               tilesD, tilesH, tilesW, ntiles);
+        });
+        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(cdiv(27 + 1, 8)), dim3(256), 0, s, part, bias_part, dw, dbias, nb, 27, 1, 1, 1, 1);
+        return check_launch("conv3d_wgrad(1->1 stencil)");
+    }
     if (cin1_ok(g) && aligned_vec4(g.dtype, dy)) {
         const size_t need = (size_t)kCin1Shares * (27 + 1) * g.co * sizeof(float);
         MRI3D_REQUIRE(ws != nullptr && ws_bytes >= need, MRI3D_EWORKSPACE, "conv3d_wgrad: workspace %zu < %zu", ws_bytes, need);
@@ -848,6 +1094,28 @@ int conv_generic_wgrad(const Mri3dConvGeom& g, const void* x, const void* dy, fl
         hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(cdiv(27 * g.co + g.co, 8)), dim3(256), 0, s, part, bias_part, dw, dbias,
                            kCin1Shares, 27, 1, g.co, 1, g.co);
         return check_launch("conv3d_wgrad(cin1)");
+    }
+    if (wgrad_co1_ok(g) && aligned_vec4(g.dtype, x)) {
+        const size_t need = (size_t)kCo1Blocks * (kSmTaps * 16 + 1) * sizeof(float);
+        MRI3D_REQUIRE(ws != nullptr && ws_bytes >= need, MRI3D_EWORKSPACE, "conv3d_wgrad: workspace %zu < %zu", ws_bytes, need);
+        const int taps = g.kd * g.kh * g.kw;
+        const int64_t nvox = (int64_t)g.n * g.dout * g.ho * g.wo;
+        const int nb = (int)std::min<int64_t>(cdiv64(nvox, 256), kCo1Blocks);
+        float* part = static_cast<float*>(ws);
+        float* bias_part = dbias ? part + (size_t)kCo1Blocks * kSmTaps * 16 : nullptr;
+#define MRI3D_CO1(CIv) hipLaunchKernelGGL((conv_wgrad_co1_kernel<T, CIv>), dim3(nb), dim3(256), 0, s, g, (const T*)x, (const T*)dy, part, bias_part)
+        MRI3D_DISPATCH_DTYPE(g.dtype, T, {
+            switch (g.ci) {
+                case 1: MRI3D_CO1(1); break;
+                case 4: MRI3D_CO1(4); break;
+                case 8: MRI3D_CO1(8); break;
+                default: MRI3D_CO1(16); break;
+            }
+        });
+#undef MRI3D_CO1
+        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(cdiv(taps * g.ci + 1, 8)), dim3(256), 0, s, part, bias_part, dw, dbias, nb, taps,
+                           g.ci, 1, g.ci, 1);
+        return check_launch("conv3d_wgrad(co1)");
     }
     if (wgrad_small_ok(g)) {
         WgradSmallPlan q = wgrad_small_plan(g);

@@ -1481,6 +1481,7 @@ static bool mfma_wgrad_plan(const Mri3dConvGeom& g, MfmaWgradPlan& p) {
         static const int cin1_mfma = getenv("MRI3D_CIN1_MFMA") ? atoi(getenv("MRI3D_CIN1_MFMA")) : 0;   // tuning aid (A/B)
         // (Co = 8: 0.25 vs 0.47 ms on 2 x 160x192x160; Co = 16 stays here: 0.22 vs 0.24 ms on 16 x 64^3)
         if (!cin1_mfma && g.co == 8 && g.y_ld % 4 == 0) return false;
+        if (!cin1_mfma && g.co == 1) return false;   // the 1 -> 1 stencil (conv_c1c1_wgrad_kernel)
         p.CK = 1;
     } else return false;
     if (p.CK >= 4 && g.x_ld % 4 != 0) return false;

@@ -112,3 +112,41 @@ def test_first_layer_conv_one_input_channel(case, dtype):
     close(wg.grad, w64.grad, tol_par, "dw")
     if bias:
         close(bg.grad, b64.grad, tol_par, "db")
+
+
+ONE_OUT = [(2, 8, (3, 1, 1), (1, 0, 0), (1, 1, 1), (9, 13, 37), True), (1, 1, (1, 3, 1), (0, 1, 0), (1, 1, 1), (4, 8, 32), False),
+           (1, 1, (1, 1, 3), (0, 0, 1), (1, 1, 1), (5, 7, 19), True), (2, 4, (1, 6, 1), (0, 2, 0), (1, 2, 1), (6, 20, 9), True),
+           (1, 16, (1, 1, 3), (0, 0, 1), (1, 1, 1), (3, 5, 70), False), (2, 1, (3, 3, 3), (1, 1, 1), (1, 1, 1), (9, 13, 37), True),
+           (1, 1, (3, 3, 3), (1, 1, 1), (1, 1, 1), (1, 1, 1), True), (1, 8, (6, 1, 1), (2, 0, 0), (2, 1, 1), (12, 6, 10), True)]
+
+
+@pytest.mark.parametrize("case", ONE_OUT, ids=lambda c: "n%d_%d-1_k%s_s%s_%s" % (c[0], c[1], "x".join(map(str, c[2])),
+                                                                                   "".join(map(str, c[4])), "x".join(map(str, c[5]))))
+def test_single_output_channel_convs(case):
+    """The autoencoder's single-channel tail (AE_model.py:110-160): few-tap convs ending in one channel (co1 weight-gradient
+    kernel) and the 1 -> 1 3x3x3 `vox` stencil (forward, data gradient, weight gradient)."""
+    nb, ci, k, pad, stride, shape, bias = case
+    g = torch.Generator().manual_seed(ci * 100 + sum(shape))
+    x = torch.randn((nb, ci) + shape, generator=g)
+    wt = torch.randn((1, ci) + k, generator=g) * 0.3
+    b = torch.randn(1, generator=g) if bias else None
+    xg = x.cuda().contiguous(memory_format=torch.channels_last_3d).requires_grad_(True)
+    wg = wt.cuda().requires_grad_(True)
+    bg = b.cuda().requires_grad_(True) if bias else None
+    yg = ops.conv3d(xg, wg, bg, stride=stride, padding=pad)
+    x64, w64 = x.double().requires_grad_(True), wt.double().requires_grad_(True)
+    b64 = b.double().requires_grad_(True) if bias else None
+    r = F.conv3d(x64, w64, b64, stride=stride, padding=pad)
+    dy = torch.randn(r.shape, generator=g)
+    yg.backward(dy.cuda())
+    r.backward(dy.double())
+
+    def close(a, ref, what):
+        err = (a.detach().double().cpu() - ref).abs().max().item()
+        assert err <= 2e-5 * (ref.abs().max().item() + 1e-6), "%s: %.3e vs scale %.3e" % (what, err, ref.abs().max().item())
+
+    close(yg, r.detach(), "y")
+    close(xg.grad, x64.grad, "dx")
+    close(wg.grad, w64.grad, "dw")
+    if bias:
+        close(bg.grad, b64.grad, "db")

@@ -12,7 +12,9 @@ from mri_epilepsy_diagnosis_amd import ops  # noqa: E402
 torch.manual_seed(0)
 worst = 0.0
 for co, shape, bias in ((8, (2, 1, 9, 13, 37), True), (16, (1, 1, 8, 16, 32), False), (8, (1, 1, 4, 8, 32), False),
-                        (16, (3, 1, 5, 7, 19), True), (8, (1, 1, 1, 1, 1), True), (8, (1, 1, 17, 9, 70), True)):
+                        (16, (3, 1, 5, 7, 19), True), (8, (1, 1, 1, 1, 1), True), (8, (1, 1, 17, 9, 70), True),
+                        (1, (2, 1, 9, 13, 37), True), (1, (1, 1, 4, 8, 32), False), (1, (1, 1, 1, 1, 1), True),
+                        (1, (2, 1, 17, 9, 70), True)):
     x = torch.randn(shape)
     w = torch.randn(co, 1, 3, 3, 3) * 0.2
     b = torch.randn(co) if bias else None

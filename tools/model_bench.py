@@ -28,7 +28,7 @@ if which == "all":
     # later steps (full-AE step 23 ms in sequence vs 10.3 ms on its own)
     import subprocess
     rc = 0
-    for cfg in ("cfg3", "cfg3ae", "cfg5", "m3d", "m3d_graph", "patch16", "patch16_c8", "cfg2", "cfg4"):
+    for cfg in ("cfg3", "cfg3_graph", "cfg3ae", "cfg3ae_graph", "cfg5", "m3d", "m3d_graph", "patch16", "patch16_c8", "cfg2", "cfg4"):
         rc |= subprocess.run([sys.executable, os.path.abspath(__file__), cfg]).returncode
     sys.exit(rc)
 dev = torch.device("cuda")
@@ -83,6 +83,31 @@ if which == "cfg3ae":
         F.mse_loss(ae(x), x).backward()
         opt2.step()
     run("cfg3 full AE MSE step, 4 x 160x192x160", 4, step3b)
+if which in ("cfg3_graph", "cfg3ae_graph"):
+    # the same two steps with forward+backward replayed as one hipGraph (parallel.CapturedStep) and the fused flat Adam:
+    # ~200 small launches per step make the eager numbers above a measurement of the host, not of the kernels
+    from mri_epilepsy_diagnosis_amd import parallel
+    torch.manual_seed(0)
+    x = torch.randn(4, 1, 160, 192, 160, device=dev, generator=g)
+    if which == "cfg3_graph":
+        enc = AE_model.AE(**AE_KWARGS_93_6_4).enc.to(dev)
+        clf = AE_model.Classificator(**dict(CLF_KWARGS, conv_pad=1, l_in=64 * 2 * 3 * 2)).to(dev)
+        mod = torch.nn.ModuleList([enc, clf])
+        y = torch.randint(0, 2, (4,), device=dev, generator=g)
+        loss_fn = lambda: F.cross_entropy(clf(enc(x)[0]), y)  # noqa: E731
+        name, lr, wd = "cfg3 encoder+clf CE step", 7e-4, 1e-4
+    else:
+        mod = AE_model.AE(**AE_KWARGS_93_6_4).to(dev)
+        loss_fn = lambda: F.mse_loss(mod(x), x)  # noqa: E731
+        name, lr, wd = "cfg3 full AE MSE step", 1e-3, 0.0
+    flat = parallel.FlatParams(mod)
+    fopt = parallel.FlatAdam(flat, lr=lr, weight_decay=wd, decoupled=False)
+    cap = parallel.CapturedStep(flat, loss_fn).capture()
+
+    def step3g():
+        cap.run()
+        fopt.step(flat.all_reduce())
+    run("%s, hipGraph fwd+bwd, 4 x 160x192x160" % name, 4, step3g)
 if which == "cfg5":
     torch.manual_seed(0)
     net = torch.nn.Sequential(cnn_model.CNN(input_shape=(32, 32, 32), n_filters=16, n_blocks=3), torch.nn.Linear(128, 2)).to(dev)
