@@ -123,6 +123,11 @@ typedef struct Mri3dPoolGeom {
 } Mri3dPoolGeom;
 int mri3d_maxpool3d_fwd(const Mri3dPoolGeom* g, const void* x, void* y, uint8_t* idx, mri3d_stream_t stream);
 int mri3d_maxpool3d_bwd(const Mri3dPoolGeom* g, const void* dy, const uint8_t* idx, void* dx, mri3d_stream_t stream);
+/* dx = maxpool3d_bwd(dy) + addend: `addend` (same storage type, voxel pitch addend_ld >= c) is the other gradient of the pool's
+ * input when that tensor also feeds a skip connection (unet.UNet encoder: `skip = x; x = pool(x)`), which autograd would
+ * otherwise sum in a separate full-resolution pass. */
+int mri3d_maxpool3d_bwd_add(const Mri3dPoolGeom* g, const void* dy, const uint8_t* idx, const void* addend,
+                            int32_t addend_ld, void* dx, mri3d_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Upsample — nn.Upsample(scale_factor=2, mode='trilinear', align_corners=False) (unet.UNet decoder),

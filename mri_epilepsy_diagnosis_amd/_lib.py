@@ -63,6 +63,7 @@ SIGNATURES = {
                                      _P, c_size_t, _P]),
     "mri3d_maxpool3d_fwd": (c_int32, [POINTER(PoolGeom), _P, _P, _P, _P]),
     "mri3d_maxpool3d_bwd": (c_int32, [POINTER(PoolGeom), _P, _P, _P, _P]),
+    "mri3d_maxpool3d_bwd_add": (c_int32, [POINTER(PoolGeom), _P, _P, _P, c_int32, _P, _P]),
     "mri3d_upsample3d_workspace_bytes": (c_size_t, [POINTER(UpGeom)]),
     "mri3d_upsample3d_fwd": (c_int32, [POINTER(UpGeom), _P, _P, _P]),
     "mri3d_upsample3d_bwd": (c_int32, [POINTER(UpGeom), _P, _P, _P, c_size_t, _P]),

@@ -102,7 +102,9 @@ maxpool_fwd_kernel(Mri3dPoolGeom g, const T* __restrict__ x, T* __restrict__ y, 
 template <typename T, int VEC>
 __global__ void __launch_bounds__(256)
 maxpool_bwd_kernel(Mri3dPoolGeom g, const T* __restrict__ dy, const uint8_t* __restrict__ idx,
-                   T* __restrict__ dx, int hch) {
+                   T* __restrict__ dx, int hch, const T* __restrict__ addend, int a_ld) {
+    // addend (optional): a second gradient of the pooled tensor's INPUT, summed in here — the encoder output feeds both the
+    // pool and the skip connection, and autograd would otherwise add the two gradients in a separate full-resolution pass
     const unsigned CV = g.c / VEC;
     const int hchunks = (g.hi + hch - 1) / hch;
     const int slabs = g.n * g.di * hchunks;
@@ -121,6 +123,12 @@ maxpool_bwd_kernel(Mri3dPoolGeom g, const T* __restrict__ dy, const uint8_t* __r
             float acc[VEC];
 #pragma unroll
             for (int j = 0; j < VEC; ++j) acc[j] = 0.f;
+            if (addend != nullptr) {
+                V<VEC> av;
+                av.load(addend + (ibase + pix) * a_ld + cv * VEC);
+#pragma unroll
+                for (int j = 0; j < VEC; ++j) acc[j] = av.v[j];
+            }
             int oh_lo = ih + g.ph - g.kh + 1; oh_lo = oh_lo <= 0 ? 0 : (oh_lo + g.sh - 1) / g.sh;
             int oh_hi = (ih + g.ph) / g.sh; if (oh_hi > g.ho - 1) oh_hi = g.ho - 1;
             int ow_lo = iw + g.pw - g.kw + 1; ow_lo = ow_lo <= 0 ? 0 : (ow_lo + g.sw - 1) / g.sw;
@@ -681,22 +689,37 @@ extern "C" int mri3d_maxpool3d_fwd(const Mri3dPoolGeom* g, const void* x, void* 
     return check_launch("maxpool3d_fwd");
 }
 
-extern "C" int mri3d_maxpool3d_bwd(const Mri3dPoolGeom* g, const void* dy, const uint8_t* idx, void* dx,
-                                   mri3d_stream_t stream) {
+static int maxpool_bwd_impl(const Mri3dPoolGeom* g, const void* dy, const uint8_t* idx, const void* addend, int32_t a_ld,
+                            void* dx, mri3d_stream_t stream) {
     int rc = pool_check(g, "maxpool3d_bwd");
     if (rc) return rc;
     MRI3D_REQUIRE(dy && dx && idx, MRI3D_EINVAL, "maxpool3d_bwd: null pointer");
+    MRI3D_REQUIRE(addend == nullptr || a_ld >= g->c, MRI3D_EINVAL, "maxpool3d_bwd: addend pitch %d < %d channels", a_ld, g->c);
     hipStream_t s = static_cast<hipStream_t>(stream);
-    bool v4 = vec_ok(g->dtype, g->c, g->x_ld, g->y_ld, dx, dy) && (reinterpret_cast<uintptr_t>(idx) & 3) == 0;
+    bool v4 = vec_ok(g->dtype, g->c, g->x_ld, g->y_ld, dx, dy) && (reinterpret_cast<uintptr_t>(idx) & 3) == 0 &&
+              (addend == nullptr || (a_ld % 4 == 0 && aligned_vec4(g->dtype, addend)));
     int hch, grid;
     slab_plan(g->n * g->di, g->hi, g->wi, g->c / (v4 ? 4 : 1), hch, grid);
     MRI3D_DISPATCH_DTYPE(g->dtype, T, {
         if (v4)
-            hipLaunchKernelGGL((maxpool_bwd_kernel<T, 4>), dim3(grid), dim3(256), 0, s, *g, (const T*)dy, idx, (T*)dx, hch);
+            hipLaunchKernelGGL((maxpool_bwd_kernel<T, 4>), dim3(grid), dim3(256), 0, s, *g, (const T*)dy, idx, (T*)dx, hch,
+                               (const T*)addend, a_ld);
         else
-            hipLaunchKernelGGL((maxpool_bwd_kernel<T, 1>), dim3(grid), dim3(256), 0, s, *g, (const T*)dy, idx, (T*)dx, hch);
+            hipLaunchKernelGGL((maxpool_bwd_kernel<T, 1>), dim3(grid), dim3(256), 0, s, *g, (const T*)dy, idx, (T*)dx, hch,
+                               (const T*)addend, a_ld);
     });
     return check_launch("maxpool3d_bwd");
+}
+
+extern "C" int mri3d_maxpool3d_bwd(const Mri3dPoolGeom* g, const void* dy, const uint8_t* idx, void* dx,
+                                   mri3d_stream_t stream) {
+    return maxpool_bwd_impl(g, dy, idx, nullptr, 0, dx, stream);
+}
+
+extern "C" int mri3d_maxpool3d_bwd_add(const Mri3dPoolGeom* g, const void* dy, const uint8_t* idx, const void* addend,
+                                       int32_t addend_ld, void* dx, mri3d_stream_t stream) {
+    MRI3D_REQUIRE(addend != nullptr, MRI3D_EINVAL, "maxpool3d_bwd_add: null addend");
+    return maxpool_bwd_impl(g, dy, idx, addend, addend_ld, dx, stream);
 }
 
 static int up_check(const Mri3dUpGeom* g, const char* who) {

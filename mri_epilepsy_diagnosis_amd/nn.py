@@ -111,6 +111,12 @@ class MaxPool3d(tnn.MaxPool3d):
             raise NotImplementedError("mri3d MaxPool3d supports floor mode, dilation 1, no indices")
         return ops.max_pool3d(x, self.kernel_size, self.stride, self.padding)
 
+    def forward_with_skip(self, x):
+        """(pool(x), x) as one autograd node — for blocks whose output also feeds a skip connection (ops.max_pool3d_skip)."""
+        if self.ceil_mode or self.return_indices or self.dilation not in (1, (1, 1, 1)):
+            raise NotImplementedError("mri3d MaxPool3d supports floor mode, dilation 1, no indices")
+        return ops.max_pool3d_skip(x, self.kernel_size, self.stride, self.padding)
+
 
 class Upsample(tnn.Upsample):
     def forward(self, x):

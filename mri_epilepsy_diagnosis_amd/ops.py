@@ -598,6 +598,47 @@ class _MaxPool3dFn(torch.autograd.Function):
         return dx, None, None, None
 
 
+class _MaxPoolSkipFn(torch.autograd.Function):
+    """`skip = x; y = max_pool3d(x)` as ONE autograd node returning (y, skip): the encoder output feeds both the pool and
+    the decoder's skip connection (unet.UNet encoder blocks), so its gradient is maxpool_bwd(dy) + dskip — summed inside the
+    pool-backward kernel instead of by a separate full-resolution autograd add (0.48 ms per step on the 16-channel level)."""
+
+    @staticmethod
+    def forward(ctx, x, kernel, stride, padding):
+        y = _MaxPool3dFn.forward(ctx, x, kernel, stride, padding)
+        return y, x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, dy, dskip):
+        if dskip is None:
+            return _MaxPool3dFn.backward(ctx, dy)
+        if dy is None:
+            return dskip, None, None, None
+        L = _lib.lib()
+        (idx,) = ctx.saved_tensors
+        dy, dy_ld = _nd(dy)
+        dskip, ds_ld = _nd(dskip)
+        if tuple(dskip.shape) != ctx.xshape or dskip.dtype != dy.dtype:
+            raise RuntimeError("max_pool3d_skip backward: skip gradient %s %s does not match the input %s %s"
+                               % (tuple(dskip.shape), dskip.dtype, ctx.xshape, dy.dtype))
+        dx = _new(ctx.xshape, dy)
+        g0 = ctx.geom
+        g = PoolGeom(g0.n, g0.di, g0.hi, g0.wi, g0.dout, g0.ho, g0.wo, g0.c, g0.kd, g0.kh, g0.kw, g0.sd, g0.sh, g0.sw,
+                     g0.pd, g0.ph, g0.pw, g0.c, dy_ld, _dt(dy))
+        with _timed("maxpool_bwd+skip c%d" % g.c,
+                    {"flops": 0.0, "bytes": _esz(dy) * 2 * dx.numel() + (_esz(dy) + 1) * dy.numel()}):
+            check(L.mri3d_maxpool3d_bwd_add(ctypes.byref(g), _ptr(dy), _ptr(idx), _ptr(dskip), ds_ld, _ptr(dx), _stream()),
+                  "maxpool3d_bwd_add")
+        return dx, None, None, None
+
+
+def max_pool3d_skip(x, kernel_size, stride=None, padding=0):
+    """(max_pool3d(x), x): use the second output for the skip connection so that both gradients meet in one kernel."""
+    k = _triple(kernel_size)
+    s = _triple(stride) if stride is not None else k
+    return _MaxPoolSkipFn.apply(x, k, s, _triple(padding))
+
+
 def max_pool3d(x, kernel_size, stride=None, padding=0):
     k = _triple(kernel_size)
     s = _triple(stride) if stride is not None else k

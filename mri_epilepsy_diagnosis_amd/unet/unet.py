@@ -72,7 +72,8 @@ class EncodingBlock(tnn.Module):
         x = self.conv2(self.conv1(x), skip_out)
         if self.downsample is None:
             return x
-        return self.downsample(x), x
+        # (pooled, skip) from one autograd node: the two gradients of x are summed inside the pool-backward kernel
+        return self.downsample.forward_with_skip(x)
 
     @property
     def out_channels(self):

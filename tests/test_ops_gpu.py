@@ -239,6 +239,42 @@ def test_max_pool3d(c, sp, k, s):
     assert_close(to_ncdhw(xd.grad), xr.grad, rel=1e-6, what="dx")
 
 
+@pytest.mark.parametrize("c,sp,pad", [(16, (6, 8, 10), 0), (8, (5, 7, 9), 8), (3, (4, 4, 6), 0), (32, (2, 2, 2), 16)])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
+def test_max_pool3d_skip_sums_both_gradients_in_the_pool_kernel(c, sp, pad, dtype):
+    """(pool(x), x) as one node (unet.UNet encoder: `skip = x; x = pool(x)`): outputs equal the two-op form, and the input
+    gradient equals maxpool_bwd(dy) + dskip — also when dskip arrives as a pitched channel slice and when one is missing."""
+    x = seeded_randn(3, (2, c, *sp))
+    if dtype == torch.bfloat16:
+        x = x.to(dtype).float()
+    xr = x.clone().requires_grad_(True)
+    yr = F.max_pool3d(xr, 2)
+    gy, gs = seeded_randn(4, tuple(yr.shape)), seeded_randn(5, tuple(x.shape))
+    if dtype == torch.bfloat16:
+        gy, gs = gy.to(dtype).float(), gs.to(dtype).float()
+    (yr * gy).sum().backward(retain_graph=True)
+    dpool = xr.grad.clone()
+    xd = _dev(x).to(dtype).requires_grad_(True)
+    yd, skip = ops.max_pool3d_skip(xd, 2)
+    assert torch.equal(to_ncdhw(yd).float(), yr.detach()) and skip.data_ptr() == xd.data_ptr() and torch.equal(skip, xd)
+    gbuf = torch.zeros(2, c + pad, *sp, device="cuda", dtype=dtype).contiguous(memory_format=torch.channels_last_3d)
+    gbuf[:, pad:] = gs.cuda().to(dtype)
+    torch.autograd.backward([yd, skip], [_dev(gy, False).to(dtype), gbuf[:, pad:]])
+    want = dpool + gs
+    tol = 1e-6 if dtype == torch.float32 else 8e-3            # bf16: one rounding of the sum
+    assert_close(to_ncdhw(xd.grad).float(), want, rel=tol, what="dx (pool + skip)")
+    # only one of the two outputs used
+    for use in ("pool", "skip"):
+        xd2 = _dev(x).to(dtype).requires_grad_(True)
+        y2, s2 = ops.max_pool3d_skip(xd2, 2)
+        if use == "pool":
+            y2.backward(_dev(gy, False).to(dtype))
+            assert_close(to_ncdhw(xd2.grad).float(), dpool, rel=tol, what="dx (pool only)")
+        else:
+            s2.backward(gs.cuda().to(dtype).contiguous(memory_format=torch.channels_last_3d))
+            assert_close(to_ncdhw(xd2.grad).float(), gs, rel=tol, what="dx (skip only)")
+
+
 def test_max_pool3d_ties_pick_first_like_torch():
     x = torch.zeros(1, 4, 4, 4, 4)
     xr = x.clone().requires_grad_(True)
