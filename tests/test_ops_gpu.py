@@ -254,7 +254,7 @@ def test_max_pool3d_skip_sums_both_gradients_in_the_pool_kernel(c, sp, pad, dtyp
         gy, gs = gy.to(dtype).float(), gs.to(dtype).float()
     (yr * gy).sum().backward(retain_graph=True)
     dpool = xr.grad.clone()
-    xd = _dev(x).to(dtype).requires_grad_(True)
+    xd = _dev(x, False).to(dtype).requires_grad_(True)
     yd, skip = ops.max_pool3d_skip(xd, 2)
     assert torch.equal(to_ncdhw(yd).float(), yr.detach()) and skip.data_ptr() == xd.data_ptr() and torch.equal(skip, xd)
     gbuf = torch.zeros(2, c + pad, *sp, device="cuda", dtype=dtype).contiguous(memory_format=torch.channels_last_3d)
@@ -265,7 +265,7 @@ def test_max_pool3d_skip_sums_both_gradients_in_the_pool_kernel(c, sp, pad, dtyp
     assert_close(to_ncdhw(xd.grad).float(), want, rel=tol, what="dx (pool + skip)")
     # only one of the two outputs used
     for use in ("pool", "skip"):
-        xd2 = _dev(x).to(dtype).requires_grad_(True)
+        xd2 = _dev(x, False).to(dtype).requires_grad_(True)
         y2, s2 = ops.max_pool3d_skip(xd2, 2)
         if use == "pool":
             y2.backward(_dev(gy, False).to(dtype))
