@@ -14,7 +14,7 @@ import ctypes
 import torch
 import torch.distributed as dist
 
-from . import _lib
+from . import _lib, ops
 
 
 class FlatParams:
@@ -39,6 +39,8 @@ class FlatParams:
             self.flat[off:off + n].copy_(p.data.reshape(-1))
             p.data = self.flat[off:off + n].view(p.shape)
             p.grad = self.grad[off:off + n].view(p.shape)
+            # the ops' backward writes this parameter's gradient straight into the view (ops.GradSink): no AccumulateGrad add
+            p._mri3d_grad_sink = ops.GradSink(p.grad)
             off += n
 
     def zero_grad(self):
@@ -48,6 +50,10 @@ class FlatParams:
             n = p.numel()
             if p.grad is None or p.grad.data_ptr() != self.grad.data_ptr() + off * self.grad.element_size():
                 p.grad = self.grad[off:off + n].view(p.shape)
+            sink = getattr(p, "_mri3d_grad_sink", None)
+            if sink is None or sink.view.data_ptr() != p.grad.data_ptr():
+                p._mri3d_grad_sink = sink = ops.GradSink(p.grad)
+            sink.fresh = True      # zeroed: the next gradient of this parameter is written, not added
             off += n
 
     def all_reduce(self, group=None):

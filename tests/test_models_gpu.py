@@ -408,3 +408,43 @@ def test_validate_dsc_asd_device_counts_equal_host_metrics():
     d2, _, _, i2 = routine.validate_dsc_asd(net, routine.synthetic_loader(3, 1, (32, 48, 32), seed=5, foreground=0.3),
                                             surface_metrics=lambda s, p: (0.0, 0.0))
     assert d2 == dsc and i2 == iou
+
+
+def test_flat_params_gradient_sinks_match_plain_autograd():
+    """parallel.FlatParams makes the ops write parameter gradients straight into the flat buffer (ops.GradSink) instead of
+    through AccumulateGrad: same numbers as plain autograd, shared parameters and repeated backward calls accumulate, and a
+    dropped .grad falls back to autograd's own path."""
+    from mri_epilepsy_diagnosis_amd import parallel
+    from mri_epilepsy_diagnosis_amd.segmentation.models.modified_3dunet import Modified3DUNet
+    torch.manual_seed(0)
+    x = torch.randn(1, 1, 16, 16, 16, device="cuda")
+    t = (torch.rand(1, 1, 16, 16, 16, device="cuda") < 0.3).float()
+    for make in (lambda: UNet(in_channels=1, out_classes=2, dimensions=3, num_encoding_blocks=2, out_channels_first_layer=8,
+                              normalization="batch", upsampling_type="linear", padding=True, activation="PReLU"),
+                 lambda: Modified3DUNet(1, 2, 8)):          # the second one applies some convs twice (shared weights)
+        torch.manual_seed(1)
+        a = make().cuda()
+        torch.manual_seed(1)
+        b = make().cuda()
+        for m in (a, b):
+            m.eval()                                          # no dropout randomness between the two copies
+        ops.softmax_dice_loss(a(x), t).backward()
+        flat = parallel.FlatParams(b)
+        flat.zero_grad()
+        ops.softmax_dice_loss(b(x), t).backward()
+        for (name, pa), pb in zip(a.named_parameters(), b.parameters()):
+            assert pb.grad.data_ptr() >= flat.grad.data_ptr() and torch.equal(pa.grad, pb.grad), name
+        # a second backward without zero_grad accumulates; with zero_grad it starts over
+        ops.softmax_dice_loss(b(x), t).backward()
+        for (name, pa), pb in zip(a.named_parameters(), b.parameters()):
+            assert torch.allclose(pb.grad, 2 * pa.grad, rtol=1e-6, atol=1e-12), name
+        flat.zero_grad()
+        ops.softmax_dice_loss(b(x), t).backward()
+        for (name, pa), pb in zip(a.named_parameters(), b.parameters()):
+            assert torch.equal(pa.grad, pb.grad), name
+        # a caller that drops .grad gets autograd's own gradient tensors
+        for p in b.parameters():
+            p.grad = None
+        ops.softmax_dice_loss(b(x), t).backward()
+        for (name, pa), pb in zip(a.named_parameters(), b.parameters()):
+            assert torch.equal(pa.grad, pb.grad), name
