@@ -437,7 +437,7 @@ def test_flat_params_gradient_sinks_match_plain_autograd():
         # a second backward without zero_grad accumulates; with zero_grad it starts over
         ops.softmax_dice_loss(b(x), t).backward()
         for (name, pa), pb in zip(a.named_parameters(), b.parameters()):
-            assert torch.allclose(pb.grad, 2 * pa.grad, rtol=1e-6, atol=1e-12), name
+            assert torch.allclose(pb.grad, 2 * pa.grad, rtol=1e-5, atol=1e-9), name    # (g + g1) + g2 vs 2 g: rounding only
         flat.zero_grad()
         ops.softmax_dice_loss(b(x), t).backward()
         for (name, pa), pb in zip(a.named_parameters(), b.parameters()):
