@@ -367,7 +367,12 @@ conv_mfma_fwd2_kernel(const T* __restrict__ x, const float* __restrict__ wp, con
         float* bufn = lds + ((it + 1) & 1) * BUF;
         const bool has_next = it + 1 < nitems;
         Item nxt = cur;
-        if (has_next) nxt = decode(it + 1);
+        // the next item is the next chunk of the same tile, or chunk 0 of this workgroup's next tile: only the second case
+        // pays for the five runtime divisions of decode() (a burst of ~150 scalar instructions that the MFMAs do not hide)
+        if (has_next) {
+            if (cur.ch + 1 < nchunks) nxt.ch = cur.ch + 1;
+            else nxt = decode(it + 1);
+        }
         const T* fbn = halo_origin(nxt);
 
         const float* wt = wp + ((size_t)cur.ch * TG * NTT + cur.nt0) * 256 + lane * 4;

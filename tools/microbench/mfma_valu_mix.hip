@@ -41,6 +41,35 @@ __global__ void __launch_bounds__(256) mix_kernel(float* out, int iters, float a
     out[blockIdx.x * blockDim.x + threadIdx.x] = s;
 }
 
+// S scalar-ALU instructions (s_mul_i32 / s_add_i32 on four independent scalar registers) per 16 MFMAs: the staging address
+// arithmetic of the conv kernels is mostly scalar (239 SALU instructions per 448 MFMAs in conv_mfma_fwd2_kernel<float,1>)
+template <int S>
+__global__ void __launch_bounds__(256) mix_salu_kernel(float* out, int iters, float a0, float b0) {
+    f32x4 acc[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float a = a0 + threadIdx.x, b = b0;
+    int s0 = iters, s1 = iters + 1, s2 = iters + 2, s3 = iters + 3;
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc[i], 0, 0, 0);
+#pragma unroll
+            for (int j = i * S / 16; j < (i + 1) * S / 16; ++j) {
+                // one SALU instruction each; the empty asm keeps the compiler from folding the chain
+                if ((j & 3) == 0) { s0 = s0 * 3; asm volatile("" : "+s"(s0)); }
+                else if ((j & 3) == 1) { s1 = s1 + 7; asm volatile("" : "+s"(s1)); }
+                else if ((j & 3) == 2) { s2 = s2 * 5; asm volatile("" : "+s"(s2)); }
+                else { s3 = s3 + 9; asm volatile("" : "+s"(s3)); }
+            }
+        }
+    }
+    float s = (float)(s0 + s1 + s2 + s3);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) s += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+
 template <typename K>
 static double run(K kern, float* out, int grid, int iters) {
     hipEvent_t e0, e1;
@@ -54,6 +83,8 @@ static double run(K kern, float* out, int grid, int iters) {
     hipEventSynchronize(e1);
     float ms = 0.f;
     hipEventElapsedTime(&ms, e0, e1);
+    hipError_t err = hipGetLastError();
+    if (err != hipSuccess) printf("  launch error: %s\n", hipGetErrorString(err));
     return ms;
 }
 
@@ -69,6 +100,12 @@ int main() {
     }
     ROW(0, false) ROW(8, false) ROW(16, false) ROW(32, false) ROW(64, false) ROW(128, false)
     ROW(8, true) ROW(16, true) ROW(32, true) ROW(64, true)
+#define SROW(S)                                                                                                     \
+    {                                                                                                               \
+        double ms = run(mix_salu_kernel<S>, out, grid, iters);                                                      \
+        printf("s_mul/s_add  x %3d per 16 MFMAs: %.2f ms  MFMA rate %.1f TFLOP/s\n", S, ms, mfma_flops / ms / 1e9);       \
+    }
+    SROW(0) SROW(8) SROW(16) SROW(32) SROW(64) SROW(128)
     hipFree(out);
     return 0;
 }
