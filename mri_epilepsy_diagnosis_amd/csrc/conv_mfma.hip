@@ -1272,6 +1272,13 @@ conv_mfma_wgrad_bf16_kernel(const bf16_t* __restrict__ x, const bf16_t* __restri
 // lane by register renaming.  Same accumulators and partial layout as v4.
 constexpr int FTW = 16;   // voxels per line
 
+// 16-byte load through an explicitly GLOBAL pointer (global_load_dwordx4: vmcnt only, never lgkmcnt)
+__device__ __forceinline__ float4 ldg4(const float* p) {
+    typedef float gf32x4 __attribute__((ext_vector_type(4)));
+    const gf32x4 v = *(const __attribute__((address_space(1))) gf32x4*)p;
+    return make_float4(v[0], v[1], v[2], v[3]);
+}
+
 template <bool BIAS>
 __global__ void __launch_bounds__(256, 2)
 conv_mfma_wgrad6_kernel(const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ part, int N, int D,
@@ -1314,18 +1321,22 @@ conv_mfma_wgrad6_kernel(const float* __restrict__ x, const float* __restrict__ d
             const int row = s_row + 16 * u;
             const int gd = d0 - 1 + row / BHH, gh = h0 - 1 + row % BHH;
             const bool rok = (unsigned)gd < (unsigned)D && (unsigned)gh < (unsigned)H;
+            // loads are UNCONDITIONAL from a clamped (always valid) address and explicitly GLOBAL: a load inside a branch
+            // came out as flat_load, which counts on lgkmcnt as well — the first LDS wait of the row loop then also waited
+            // for the whole prefetch, i.e. the next tile's HBM latency was not hidden behind this tile's MFMAs
             const float* src = x + ((((int64_t)n * D + (rok ? gd : 0)) * H + (rok ? gh : 0)) * W) * x_ld + cit * 16 + 4 * s_q;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const int gw = w0 + 4 * s_wg + j;
-                vx[u][j] = (rok && gw < W) ? *reinterpret_cast<const float4*>(src + (int64_t)gw * x_ld) : zero4;
+                const float4 t = ldg4(src + (int64_t)min(gw, W - 1) * x_ld);
+                vx[u][j] = (rok && gw < W) ? t : zero4;
             }
         }
         {   // ---- X halo voxels
             const int gd = d0 - 1 + h_row / BHH, gh = h0 - 1 + h_row % BHH, gw = h_side ? w0 + FTW : w0 - 1;
             const bool ok = (unsigned)gd < (unsigned)D && (unsigned)gh < (unsigned)H && (unsigned)gw < (unsigned)W;
-            vh = zero4;
-            if (ok) vh = *reinterpret_cast<const float4*>(x + ((((int64_t)n * D + gd) * H + gh) * W + gw) * x_ld + cit * 16 + 4 * h_q);
+            const float4 t = ldg4(x + ((((int64_t)n * D + (ok ? gd : 0)) * H + (ok ? gh : 0)) * W + (ok ? gw : 0)) * x_ld + cit * 16 + 4 * h_q);
+            vh = ok ? t : zero4;
         }
         if (tid < BYR * 16) {   // ---- dY
             const int gd = d0 + s_row / BTH, gh = h0 + s_row % BTH;
@@ -1335,7 +1346,8 @@ conv_mfma_wgrad6_kernel(const float* __restrict__ x, const float* __restrict__ d
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const int gw = w0 + 4 * s_wg + j;
-                vy[j] = (rok && gw < W) ? *reinterpret_cast<const float4*>(src + (int64_t)gw * y_ld) : zero4;
+                const float4 t = ldg4(src + (int64_t)min(gw, W - 1) * y_ld);
+                vy[j] = (rok && gw < W) ? t : zero4;
             }
         }
     };
