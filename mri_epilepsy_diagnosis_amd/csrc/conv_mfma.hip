@@ -1124,6 +1124,13 @@ __device__ __forceinline__ void transpose8x8_bf16(const uint4 (&v)[8], uint4 (&o
     }
 }
 
+// 16-byte load of bf16 data through an explicitly GLOBAL pointer (global_load_dwordx4: vmcnt only, never lgkmcnt)
+__device__ __forceinline__ uint4 ldg4u(const bf16_t* p) {
+    typedef unsigned gu32x4 __attribute__((ext_vector_type(4)));
+    const gu32x4 v = *(const __attribute__((address_space(1))) gu32x4*)p;
+    return make_uint4(v[0], v[1], v[2], v[3]);
+}
+
 template <bool BIAS>
 __global__ void __launch_bounds__(256, 2)
 conv_mfma_wgrad_bf16_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ dy, float* __restrict__ part, int N,
@@ -1175,7 +1182,8 @@ conv_mfma_wgrad_bf16_kernel(const bf16_t* __restrict__ x, const bf16_t* __restri
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 const int gw = w0 + 8 * s_wg + j;
-                v[j] = (rok && gw < W) ? *reinterpret_cast<const uint4*>(src + (int64_t)gw * x_ld) : zero4;
+                const uint4 t = ldg4u(src + (int64_t)min(gw, W - 1) * x_ld);   // unconditional, explicitly global (see wgrad6)
+                v[j] = (rok && gw < W) ? t : zero4;
             }
             transpose8x8_bf16(v, o);
 #pragma unroll
@@ -1186,8 +1194,8 @@ conv_mfma_wgrad_bf16_kernel(const bf16_t* __restrict__ x, const bf16_t* __restri
             const int gd = d0 - 1 + h_row / BHH, gh = h0 - 1 + h_row % BHH, gw = h_side ? w0 + BTW : w0 - 1;
             const int c0 = cit * 16 + 8 * h_half;
             const bool ok = (unsigned)gd < (unsigned)D && (unsigned)gh < (unsigned)H && (unsigned)gw < (unsigned)W && c0 < Ci;
-            uint4 hv = zero4;
-            if (ok) hv = *reinterpret_cast<const uint4*>(x + ((((int64_t)n * D + gd) * H + gh) * W + gw) * x_ld + c0);
+            const uint4 ht = ldg4u(x + ((((int64_t)n * D + (ok ? gd : 0)) * H + (ok ? gh : 0)) * W + (ok ? gw : 0)) * x_ld + (c0 < Ci ? c0 : 0));
+            const uint4 hv = ok ? ht : zero4;
             const unsigned* hw = reinterpret_cast<const unsigned*>(&hv);
 #pragma unroll
             for (int c = 0; c < 8; ++c) {
@@ -1204,7 +1212,8 @@ conv_mfma_wgrad_bf16_kernel(const bf16_t* __restrict__ x, const bf16_t* __restri
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 const int gw = w0 + 8 * s_wg + j;
-                v[j] = (rok && gw < W) ? *reinterpret_cast<const uint4*>(src + (int64_t)gw * y_ld) : zero4;
+                const uint4 t = ldg4u(src + (int64_t)min(gw, W - 1) * y_ld);
+                v[j] = (rok && gw < W) ? t : zero4;
             }
             transpose8x8_bf16(v, o);
 #pragma unroll
