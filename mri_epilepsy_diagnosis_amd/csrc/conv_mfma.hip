@@ -1318,6 +1318,19 @@ conv_mfma_wgrad6_kernel(const float* __restrict__ x, const float* __restrict__ d
     // next tile's pieces: fetched into registers while the current tile is multiplied (HBM/L2 latency hidden), written to
     // the single LDS tile between two barriers after it
     float4 vx[2][4], vh, vy[4];
+    // Per-lane element offsets of its pieces from the tile's origin voxels, computed once: a piece's address is then a
+    // wave-uniform tile base + a 32-bit lane offset (+ j voxels), with no per-tile vector multiplies or 64-bit mads (18
+    // v_mul_lo_u32 + 22 64-bit ops per tile before — quarter-rate work the MFMAs do not hide).  X origin = voxel
+    // (d0-1, h0-1, w0-1), dY origin = (d0, h0, w0); out-of-volume pieces read the tile's first output voxel (always valid).
+    unsigned xrel[2], yrel;
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int row = s_row + 16 * u;
+        xrel[u] = (unsigned)((((row / BHH) * H + row % BHH) * W + 1 + 4 * s_wg) * x_ld + 4 * s_q);
+    }
+    const unsigned hrel = (unsigned)((((h_row / BHH) * H + h_row % BHH) * W + (h_side ? FTW + 1 : 0)) * x_ld + 4 * h_q);
+    const unsigned xsafe = (unsigned)(((H + 1) * W + 1) * x_ld);
+    yrel = (unsigned)((((s_row / BTH) * H + s_row % BTH) * W + 4 * s_wg) * y_ld + 4 * s_q);
     auto load_tile = [&](int tile) {
         const int w0 = (tile % tilesW) * FTW;
         tile /= tilesW;
@@ -1325,38 +1338,36 @@ conv_mfma_wgrad6_kernel(const float* __restrict__ x, const float* __restrict__ d
         tile /= tilesH;
         const int d0 = (tile % tilesD) * BTD;
         const int n = tile / tilesD;
+        // wave-uniform bases; the X base may point before the tensor (d0 = 0 ...) and is only dereferenced at valid offsets
+        const float* xb = x + ((((int64_t)n * D + d0 - 1) * H + h0 - 1) * W + w0 - 1) * x_ld + cit * 16;
+        const int c0 = cob * 16 + 4 * s_q;
+        const float* yb = dy + ((((int64_t)n * D + d0) * H + h0) * W + w0) * y_ld + cob * 16;
 #pragma unroll
         for (int u = 0; u < 2; ++u) {   // ---- X
             const int row = s_row + 16 * u;
             const int gd = d0 - 1 + row / BHH, gh = h0 - 1 + row % BHH;
             const bool rok = (unsigned)gd < (unsigned)D && (unsigned)gh < (unsigned)H;
-            // loads are UNCONDITIONAL from a clamped (always valid) address and explicitly GLOBAL: a load inside a branch
-            // came out as flat_load, which counts on lgkmcnt as well — the first LDS wait of the row loop then also waited
-            // for the whole prefetch, i.e. the next tile's HBM latency was not hidden behind this tile's MFMAs
-            const float* src = x + ((((int64_t)n * D + (rok ? gd : 0)) * H + (rok ? gh : 0)) * W) * x_ld + cit * 16 + 4 * s_q;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const int gw = w0 + 4 * s_wg + j;
-                const float4 t = ldg4(src + (int64_t)min(gw, W - 1) * x_ld);
-                vx[u][j] = (rok && gw < W) ? t : zero4;
+                const bool ok = rok && w0 + 4 * s_wg + j < W;
+                const float4 t = ldg4(xb + (ok ? xrel[u] + (unsigned)(j * x_ld) : xsafe));
+                vx[u][j] = ok ? t : zero4;
             }
         }
         {   // ---- X halo voxels
             const int gd = d0 - 1 + h_row / BHH, gh = h0 - 1 + h_row % BHH, gw = h_side ? w0 + FTW : w0 - 1;
             const bool ok = (unsigned)gd < (unsigned)D && (unsigned)gh < (unsigned)H && (unsigned)gw < (unsigned)W;
-            const float4 t = ldg4(x + ((((int64_t)n * D + (ok ? gd : 0)) * H + (ok ? gh : 0)) * W + (ok ? gw : 0)) * x_ld + cit * 16 + 4 * h_q);
+            const float4 t = ldg4(xb + (ok ? hrel : xsafe));
             vh = ok ? t : zero4;
         }
         if (tid < BYR * 16) {   // ---- dY
             const int gd = d0 + s_row / BTH, gh = h0 + s_row % BTH;
-            const int c0 = cob * 16 + 4 * s_q;
             const bool rok = gd < D && gh < H && c0 < Co;       // host guarantees Co % 4 == 0
-            const float* src = dy + ((((int64_t)n * D + (rok ? gd : 0)) * H + (rok ? gh : 0)) * W) * y_ld + (c0 < Co ? c0 : 0);
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const int gw = w0 + 4 * s_wg + j;
-                const float4 t = ldg4(src + (int64_t)min(gw, W - 1) * y_ld);
-                vy[j] = (rok && gw < W) ? t : zero4;
+                const bool ok = rok && w0 + 4 * s_wg + j < W;
+                const float4 t = ldg4(yb + (ok ? yrel + (unsigned)(j * y_ld) : 0u));
+                vy[j] = ok ? t : zero4;
             }
         }
     };
