@@ -1468,8 +1468,18 @@ wgrad_mfma_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw,
     const int e = blockIdx.x * 64 + el;
     const size_t pstride = (size_t)nelem;
     double s = 0.0;
-    if (e < nelem)
-        for (int q = ql; q < P; q += 4) s += (double)part[(size_t)q * pstride + e];
+    if (e < nelem) {
+        double s1 = 0.0, s2 = 0.0, s3 = 0.0;   // four independent chains: more partial loads in flight
+        int q = ql;
+        for (; q + 12 < P; q += 16) {
+            s += (double)part[(size_t)q * pstride + e];
+            s1 += (double)part[(size_t)(q + 4) * pstride + e];
+            s2 += (double)part[(size_t)(q + 8) * pstride + e];
+            s3 += (double)part[(size_t)(q + 12) * pstride + e];
+        }
+        for (; q < P; q += 4) s += (double)part[(size_t)q * pstride + e];
+        s = (s + s1) + (s2 + s3);
+    }
     red[threadIdx.x] = s;
     __syncthreads();
     if (ql != 0 || e >= nelem) return;

@@ -26,7 +26,8 @@ struct NormPlan {
 };
 
 constexpr int kNormMaxBlocks = 1024;  // 4 blocks/CU of streaming work; keeps the finalize pass short
-constexpr int kFinQL = 16;            // partial-sum lanes per channel in the finalize kernels
+constexpr int kFinQL = 64;            // partial-sum lanes per channel in the finalize kernels: with 16 lanes (64 dependent
+                                      // loads + adds each over 1024 partials) the two finalize passes took 20 us per launch
 
 static NormPlan norm_plan(const Mri3dNormGeom& g, bool al) {
     NormPlan p;
@@ -128,7 +129,7 @@ norm_stats_finalize_kernel(const T* __restrict__ x, const double* __restrict__ p
                            float* __restrict__ mean, float* __restrict__ invstd,
                            float* __restrict__ running_mean, float* __restrict__ running_var,
                            float momentum, float eps, int C, int ld, int64_t gvox, int nblk, int groups) {
-    // 256 threads = 16 (group,channel) slots x kFinQL partial lanes
+    // 256 threads = 4 (group,channel) slots x kFinQL partial lanes
     __shared__ double ra[256], rb[256];
     const int slot = threadIdx.x / kFinQL, ql = threadIdx.x % kFinQL;
     const int i = blockIdx.x * (256 / kFinQL) + slot;
@@ -137,10 +138,20 @@ norm_stats_finalize_kernel(const T* __restrict__ x, const double* __restrict__ p
     double a = 0.0, b = 0.0;
     if (ok) {
         const double* p = part + ((size_t)group * nblk * C + c) * 2;
-        for (int q = ql; q < nblk; q += kFinQL) {
+        double a1 = 0.0, b1 = 0.0;   // two independent chains: more partial loads in flight
+        int q = ql;
+        for (; q + kFinQL < nblk; q += 2 * kFinQL) {
+            a += p[(size_t)q * C * 2];
+            b += p[(size_t)q * C * 2 + 1];
+            a1 += p[(size_t)(q + kFinQL) * C * 2];
+            b1 += p[(size_t)(q + kFinQL) * C * 2 + 1];
+        }
+        if (q < nblk) {
             a += p[(size_t)q * C * 2];
             b += p[(size_t)q * C * 2 + 1];
         }
+        a += a1;
+        b += b1;
     }
     ra[threadIdx.x] = a;
     rb[threadIdx.x] = b;
@@ -339,11 +350,24 @@ norm_act_bwd_sums_kernel(const double* __restrict__ part, float* __restrict__ su
     double a = 0.0, b = 0.0, d = 0.0;
     if (ok) {
         const double* p = part + ((size_t)group * nblk * C + c) * 3;
-        for (int q = ql; q < nblk; q += kFinQL) {
+        double a1 = 0.0, b1 = 0.0, d1 = 0.0;
+        int q = ql;
+        for (; q + kFinQL < nblk; q += 2 * kFinQL) {
+            a += p[(size_t)q * C * 3];
+            b += p[(size_t)q * C * 3 + 1];
+            d += p[(size_t)q * C * 3 + 2];
+            a1 += p[(size_t)(q + kFinQL) * C * 3];
+            b1 += p[(size_t)(q + kFinQL) * C * 3 + 1];
+            d1 += p[(size_t)(q + kFinQL) * C * 3 + 2];
+        }
+        if (q < nblk) {
             a += p[(size_t)q * C * 3];
             b += p[(size_t)q * C * 3 + 1];
             d += p[(size_t)q * C * 3 + 2];
         }
+        a += a1;
+        b += b1;
+        d += d1;
     }
     r0[threadIdx.x] = a;
     r1[threadIdx.x] = b;
