@@ -94,7 +94,24 @@ norm_stats_kernel(const T* __restrict__ x, double* __restrict__ part, int C, int
     for (int j = 0; j < VEC; ++j) { s[j] = 0.0; ss[j] = 0.0; k[j] = 0.f; }
     if (active) {
         Ld<VEC>::load(xg + c0, k);  // shift = first voxel of the group: removes E[x^2]-E[x]^2 cancellation
-        for (int64_t v = (int64_t)blockIdx.x * VT + vt; v < gvox; v += (int64_t)gridDim.x * VT) {
+        // four voxel rows per trip: the loads are independent, so four 16-byte requests per lane are in flight (one at a
+        // time left this read-only pass at 4.2 TB/s); the sums still run in voxel order
+        const int64_t step = (int64_t)gridDim.x * VT;
+        int64_t v = (int64_t)blockIdx.x * VT + vt;
+        for (; v + 3 * step < gvox; v += 4 * step) {
+            float xv[4][VEC];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) Ld<VEC>::load(xg + (v + u * step) * ld + c0, xv[u]);
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int j = 0; j < VEC; ++j) {
+                    const double d = (double)(xv[u][j] - k[j]);
+                    s[j] += d;
+                    ss[j] = fma(d, d, ss[j]);
+                }
+        }
+        for (; v < gvox; v += step) {
             float xv[VEC];
             Ld<VEC>::load(xg + v * ld + c0, xv);
 #pragma unroll
