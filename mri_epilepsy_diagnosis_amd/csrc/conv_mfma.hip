@@ -31,6 +31,18 @@ constexpr int HVOX = HD * HH * HW;                   // 1080 voxels
 
 __host__ __device__ constexpr int tap_groups(int CK) { return CK == 16 ? 27 : 14; }
 
+// Tap pairing of the two-taps-per-k-step kernels (8-channel fp32 chunks, 16-channel bf16 chunks): tap group tg carries taps
+// pair_tap(tg, 0) in k-groups 0,1 and pair_tap(tg, 1) in k-groups 2,3 (27 = padding, zero weights).  The pairs are chosen so
+// that the three groups of a CLASS differ only in kh, i.e. by ONE ROW of the halo tile:
+//   groups 3c+kh (c = kd = 0..2):  (kd, kh, 0) | (kd, kh, 1)          groups 9+kh:  (0, kh, 2) | (1, kh, 2)
+//   group 12:  (2, 0, 2) | (2, 1, 2)                                  group 13:     (2, 2, 2) | padding
+// A-fragment (voxel rows) of group (class, kh), output row m == fragment of group (class, 0), row m + kh, so a wave needs 10
+// LDS fragments per class instead of 3 x 8 (conv_mfma_fwd2_kernel, one N-tile): 56 instead of 112 ds_read_b128 per chunk.
+__host__ __device__ constexpr int pair_tap(int tg, int half) {
+    return tg < 9 ? ((tg / 3) * 3 + tg % 3) * 3 + half
+                  : (tg < 12 ? (half * 3 + (tg - 9)) * 3 + 2 : (tg == 12 ? (6 + half) * 3 + 2 : (half == 0 ? 26 : 27)));
+}
+
 // Bijective XCD-aware remap (cdna_hip_programming.md T1): blocks b and b+8 share an XCD; give each XCD a contiguous
 // range of tiles so that spatial neighbours (which share halo voxels) hit the same L2.
 __device__ __forceinline__ int xcd_remap(int b, int n) {
@@ -42,7 +54,7 @@ __device__ __forceinline__ int xcd_remap(int b, int n) {
 // Wp[chunk][tg][nt][lane][s]:  value = W'(tap, kc, nc) with
 //   nc = nt*16 + (lane & 15)
 //   CK == 16: tap = tg,                 kc = chunk*16 + 4*(lane>>4) + s
-//   CK ==  8: tap = 2*tg + (lane>>5),   kc = chunk*8  + 4*((lane>>4)&1) + s      (tap 27 -> 0)
+//   CK ==  8: tap = pair_tap(tg, lane>>5), kc = chunk*8  + 4*((lane>>4)&1) + s   (tap 27 -> 0)
 //   forward: W'(tap,kc,nc) = W[nc][kc][tap];  dgrad: W'(tap,kc,nc) = W[kc][nc][26 - tap]
 __global__ void pack_w_mfma_kernel(const float* __restrict__ w, float* __restrict__ wp, int Co, int Ci, int dgrad,
                                    int CK, int NTT, int nchunks) {
@@ -62,7 +74,7 @@ __global__ void pack_w_mfma_kernel(const float* __restrict__ w, float* __restric
             tap = tg;
             kc = chunk * 16 + 4 * (lane >> 4) + s;
         } else {
-            tap = 2 * tg + (lane >> 5);
+            tap = pair_tap(tg, lane >> 5);
             kc = chunk * 8 + 4 * ((lane >> 4) & 1) + s;
         }
         float v = 0.f;
@@ -75,7 +87,7 @@ __global__ void pack_w_mfma_kernel(const float* __restrict__ w, float* __restric
 
 // bf16 image for the 16x16x32 MFMA (conv_mfma_fwd2_kernel<bf16_t>): a 32-byte voxel slice holds 16 channels, so a
 // chunk is 16 channels and a lane's 16-byte fragment is 8 consecutive channels of one tap:
-//   Wp[chunk][tg][nt][lane][s], s = 0..7:  tap = 2*tg + (lane>>5), kc = chunk*16 + 8*((lane>>4)&1) + s  (tap 27 -> 0)
+//   Wp[chunk][tg][nt][lane][s], s = 0..7:  tap = pair_tap(tg, lane>>5), kc = chunk*16 + 8*((lane>>4)&1) + s  (tap 27 -> 0)
 __global__ void pack_w_mfma_bf16_kernel(const float* __restrict__ w, bf16_t* __restrict__ wp, int Co, int Ci, int dgrad,
                                         int NTT, int nchunks) {
     constexpr int TG = 14;
@@ -88,7 +100,7 @@ __global__ void pack_w_mfma_bf16_kernel(const float* __restrict__ w, bf16_t* __r
         t /= NTT;
         const int tg = t % TG, chunk = t / TG;
         const int nc = nt * 16 + (lane & 15);
-        const int tap = 2 * tg + (lane >> 5);
+        const int tap = pair_tap(tg, lane >> 5);
         const int kc = chunk * 16 + 8 * ((lane >> 4) & 1) + s;
         float v = 0.f;
         if (tap < 27 && nc < Nc && kc < Kc)
@@ -158,7 +170,7 @@ conv_mfma_fwd_kernel(const float* __restrict__ x, const float* __restrict__ wp, 
                 const int kd = tg / 9, kh = (tg / 3) % 3, kw = tg % 3;
                 return (((wv + kd) * HH + kh) * HW + (li + kw)) * CP + 4 * kq;
             } else {
-                const int ta = 2 * tg, tb = (2 * tg + 1 < 27) ? 2 * tg + 1 : 26;  // tap 27 has zero weights
+                const int ta = pair_tap(tg, 0), tb = pair_tap(tg, 1) < 27 ? pair_tap(tg, 1) : 26;  // tap 27 has zero weights
                 const int oa = ((ta / 9) * HH + (ta / 3) % 3) * HW + ta % 3;
                 const int ob = ((tb / 9) * HH + (tb / 3) % 3) * HW + tb % 3;
                 return ((wv * HH) * HW + li + ((kq >> 1) ? ob : oa)) * CP + 4 * (kq & 1);
@@ -354,9 +366,9 @@ conv_mfma_fwd2_kernel(const T* __restrict__ x, const float* __restrict__ wp, con
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) acc[m][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    // A-fragment LDS offsets of a tap group (k-groups 0,1 = tap 2t; k-groups 2,3 = tap 2t+1, tap 27 = zero weights)
+    // A-fragment LDS offsets of a tap group (k-groups 0,1 = pair_tap(tg, 0); k-groups 2,3 = pair_tap(tg, 1), tap 27 = zero weights)
     auto a_off = [&](int tg) -> int {
-        const int ta = 2 * tg, tb = (2 * tg + 1 < 27) ? 2 * tg + 1 : 26;
+        const int ta = pair_tap(tg, 0), tb = pair_tap(tg, 1) < 27 ? pair_tap(tg, 1) : 26;
         const int oa = ((ta / 9) * HH + (ta / 3) % 3) * HW + ta % 3;
         const int ob = ((tb / 9) * HH + (tb / 3) % 3) * HW + tb % 3;
         return ((wv * HH) * HW + li + ((kq >> 1) ? ob : oa)) * CP + 4 * (kq & 1);
@@ -378,13 +390,61 @@ conv_mfma_fwd2_kernel(const T* __restrict__ x, const float* __restrict__ wp, con
         const float* wt = wp + ((size_t)cur.ch * TG * NTT + cur.nt0) * 256 + lane * 4;
         const size_t wstep = (size_t)NTT * 256;
         f32x4 bq[3][NT];
-        f32x4 aq[2][TH];
         float4 sq[4];
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
             bq[0][nt] = *reinterpret_cast<const f32x4*>(wt + nt * 256);
             bq[1][nt] = *reinterpret_cast<const f32x4*>(wt + wstep + nt * 256);
         }
+        if constexpr (NT == 1) {
+            // One N-tile: every A-fragment feeds a single MFMA chain, so the LDS reads are the largest non-MFMA cost.  The tap
+            // groups come in UNITS: four classes of three groups that differ only by one halo row (pair_tap), then groups 12
+            // and 13.  A class needs 10 row fragments (rows 0..9 of its kh = 0 group; group kh, output row m uses row m + kh)
+            // instead of 3 x 8; the next unit's fragments are fetched while this unit is multiplied (two register sets).
+            constexpr int NU = 6;
+            f32x4 fr[2][TH + 2];
+            {
+                const int o0 = a_off(0);
+#pragma unroll
+                for (int i = 0; i < TH + 2; ++i) fr[0][i] = *reinterpret_cast<const f32x4*>(bufc + o0 + i * HW * CP);
+            }
+#pragma unroll
+            for (int tg = 0; tg < TG; ++tg) {
+                const int cb = tg % 3, nb = (tg + 2) % 3;
+                const int u = tg < 12 ? tg / 3 : tg - 8, ufirst = u < 4 ? 3 * u : u + 8, ng = u < 4 ? 3 : 1;
+                const int kh = tg - ufirst;   // row shift inside the class (0 for the single-group units)
+                if (tg < kStg) sq[tg & 3] = stage_load(nxt, fbn, tg);  // next chunk: global -> regs (unconditional)
+                if (tg + 2 < TG) bq[nb][0] = *reinterpret_cast<const f32x4*>(wt + (size_t)(tg + 2) * wstep);
+                if (tg >= 3 && tg - 3 < kStg) stage_store(bufn, tg - 3, sq[(tg - 3) & 3]);  // regs -> LDS
+                if (u + 1 < NU) {   // this group's share of the next unit's fragments
+                    const int nu = u + 1, nfirst = nu < 4 ? 3 * nu : nu + 8, nf = nu < 4 ? TH + 2 : TH;
+                    const int on = a_off(nfirst);
+#pragma unroll
+                    for (int i = 0; i < TH + 2; ++i)
+                        if (i >= kh * nf / ng && i < (kh + 1) * nf / ng)
+                            fr[nu & 1][i] = *reinterpret_cast<const f32x4*>(bufc + on + i * HW * CP);
+                }
+                __builtin_amdgcn_sched_barrier(0);  // keep the prefetches above this tap group's MFMAs
+                if constexpr (kBf16) {
+#pragma unroll
+                    for (int m = 0; m < TH; ++m)
+                        acc[m][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, bq[cb][0]),
+                                                                            __builtin_bit_cast(bf16x8_t, fr[u & 1][m + kh]),
+                                                                            acc[m][0], 0, 0, 0);
+                } else {
+                    // accumulator reuse distance 2 (two rows alternate over the four k-steps): the fp32 MFMA sustains its peak
+                    // when an accumulator comes back after <= 3 or >= 16 instructions, not after 4..8 (tools/microbench)
+#pragma unroll
+                    for (int m = 0; m < TH; m += 2)
+#pragma unroll
+                        for (int s = 0; s < 4; ++s) {
+                            acc[m][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(bq[cb][0][s], fr[u & 1][m + kh][s], acc[m][0], 0, 0, 0);
+                            acc[m + 1][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(bq[cb][0][s], fr[u & 1][m + 1 + kh][s], acc[m + 1][0], 0, 0, 0);
+                        }
+                }
+            }
+        } else {
+        f32x4 aq[2][TH];
         {
             const int o0 = a_off(0);
 #pragma unroll
@@ -423,6 +483,7 @@ conv_mfma_fwd2_kernel(const T* __restrict__ x, const float* __restrict__ wp, con
                         for (int m = 0; m < TH; ++m)
                             acc[m][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(bq[cb][nt][s], aq[ac][m][s], acc[m][nt], 0, 0, 0);
             }
+        }
         }
 
         if (cur.ch == nchunks - 1) {
