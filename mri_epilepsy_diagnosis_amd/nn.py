@@ -57,7 +57,8 @@ def fused_norm_act(norm, act, x, out=None):
         return ops.norm_act(x, norm.weight, norm.bias, alpha,
                             norm.running_mean if norm.track_running_stats else None,
                             norm.running_var if norm.track_running_stats else None,
-                            "batch" if use_batch else "running",
+                            ("sync" if (norm.training and ops.sync_batchnorm_reducer() is not None) else "batch")
+                            if use_batch else "running",
                             norm.momentum, norm.eps, kind, slope, out)
     if isinstance(norm, tnn.modules.instancenorm._InstanceNorm):
         if norm.track_running_stats:

@@ -467,6 +467,24 @@ def conv_transpose3d(x, weight, bias=None, stride=1, padding=0, output_padding=0
 
 _ACT_CODES = {None: ACT_NONE, "none": ACT_NONE, "relu": ACT_RELU, "leaky_relu": ACT_LEAKY, "prelu": ACT_PRELU}
 
+# Synchronised BatchNorm (SURVEY §8e "parity mode"): when a reducer is installed, training-mode BatchNorm layers take their
+# statistics over the GLOBAL batch of all data-parallel ranks, so that N ranks x 2 volumes reproduce the statistics of one
+# device with 2N volumes.  A reducer is any object with `all_reduce(t)` returning the element-wise sum of the float64 tensor
+# `t` over all ranks (parallel.SyncBatchNorm wraps torch.distributed; tests inject a fake).  Two tiny collectives per layer
+# per step (2C+1 doubles forward, 2C doubles backward); the default stays local statistics.
+_sync_bn_reducer = None
+
+
+def set_sync_batchnorm(reducer):
+    """Install (or, with None, remove) the reducer of synchronised BatchNorm; returns the previous one."""
+    global _sync_bn_reducer
+    prev, _sync_bn_reducer = _sync_bn_reducer, reducer
+    return prev
+
+
+def sync_batchnorm_reducer():
+    return _sync_bn_reducer
+
 
 class _NormActFn(torch.autograd.Function):
     """y = act(gamma * (x - mean) / sqrt(var + eps) + beta) with batch, instance, running or no statistics."""
@@ -509,6 +527,34 @@ class _NormActFn(torch.autograd.Function):
                 check(L.mri3d_norm_stats(ctypes.byref(g), _ptr(x), _ptr(mean), _ptr(invstd),
                                          _ptr(running_mean) if upd else None, _ptr(running_var) if upd else None,
                                          float(momentum), _ptr(ws), ws.numel(), _stream()), "norm_stats")
+        elif stats_mode == "sync":
+            # local moments with the statistics kernel, summed over the ranks as (count, sum x, sum x^2) in float64
+            reducer = _sync_bn_reducer
+            if reducer is None:
+                raise RuntimeError("norm_act(stats_mode='sync') needs ops.set_sync_batchnorm(reducer)")
+            mean_l = torch.empty(c, dtype=torch.float32, device=x.device)
+            invstd_l = torch.empty(c, dtype=torch.float32, device=x.device)
+            ws = _workspace(L.mri3d_norm_workspace_bytes(ctypes.byref(g)), x.device)
+            with _timed("norm_stats c%d vox%d n%d" % (c, g.vox, n), {"flops": 0.0, "bytes": _esz(x) * x.numel()}):
+                check(L.mri3d_norm_stats(ctypes.byref(g), _ptr(x), _ptr(mean_l), _ptr(invstd_l), None, None, float(momentum),
+                                         _ptr(ws), ws.numel(), _stream()), "norm_stats")
+            cnt_l = float(n * g.vox)
+            m64 = mean_l.double()
+            var_l = (1.0 / invstd_l.double() ** 2 - float(eps)).clamp_(min=0.0)
+            pack = torch.cat([torch.full((1,), cnt_l, dtype=torch.float64, device=x.device), cnt_l * m64,
+                              cnt_l * (var_l + m64 * m64)])
+            pack = reducer.all_reduce(pack)
+            cnt = pack[0]
+            gmean = pack[1:1 + c] / cnt
+            gvar = (pack[1 + c:] / cnt - gmean * gmean).clamp_(min=0.0)
+            mean = gmean.to(torch.float32).contiguous()
+            invstd = torch.rsqrt(gvar + float(eps)).to(torch.float32).contiguous()
+            if running_mean is not None:
+                with torch.no_grad():
+                    unb = gvar * (cnt / torch.clamp(cnt - 1.0, min=1.0))
+                    running_mean.mul_(1.0 - momentum).add_(momentum * gmean.to(running_mean.dtype))
+                    running_var.mul_(1.0 - momentum).add_(momentum * unb.to(running_var.dtype))
+            ctx.sync_count = cnt
         elif stats_mode == "running":
             mean = running_mean.detach().to(torch.float32).contiguous()
             invstd = torch.rsqrt(running_var.detach().to(torch.float32) + eps).contiguous()
@@ -519,6 +565,7 @@ class _NormActFn(torch.autograd.Function):
         ctx.save_for_backward(x, mean, invstd, gamma, beta, alpha)
         ctx.geom = g
         ctx.training_stats = stats_mode in ("batch", "instance", "group")
+        ctx.sync = _sync_bn_reducer if stats_mode == "sync" else None
         return y
 
     @staticmethod
@@ -544,12 +591,37 @@ class _NormActFn(torch.autograd.Function):
         dgamma = (sg if sg is not None else torch.empty_like(gamma)) if want[0] else None
         dbeta = (sb if sb is not None else torch.empty_like(beta)) if want[1] else None
         dalpha = (sa if sa is not None else torch.empty_like(alpha)) if want[2] else None
+        sync = ctx.sync
+        if sync is not None:
+            # the two batch sums of the BatchNorm gradient (sum dy', sum dy' * xhat) are exactly what the kernel reports as
+            # d(beta), d(gamma) of the frozen-statistics formula: take them locally, sum them over the ranks, then apply the
+            # two mean-subtraction terms as one more per-channel affine pass over x
+            c_ = g.c
+            s1 = dbeta if dbeta is not None else torch.empty(c_, dtype=torch.float32, device=x.device)
+            s2 = dgamma if dgamma is not None else torch.empty(c_, dtype=torch.float32, device=x.device)
+            dbeta_k, dgamma_k = s1, s2
+        else:
+            dbeta_k, dgamma_k = dbeta, dgamma
         ws = _workspace(L.mri3d_norm_workspace_bytes(ctypes.byref(g)), x.device)
         with _timed("norm_act_bwd c%d vox%d n%d" % (g.c, g.vox, g.n), {"flops": 0.0, "bytes": 5 * _esz(x) * x.numel()}):
             check(L.mri3d_norm_act_bwd(ctypes.byref(g), 1 if ctx.training_stats else 0, _ptr(x), _ptr(dy), _ptr(mean),
                                        _ptr(invstd), _ptr(gamma), _ptr(beta), _ptr(alpha) if prelu else None, _ptr(dx),
-                                       _ptr(dgamma), _ptr(dbeta), _ptr(dalpha), _ptr(ws), ws.numel(), _stream()),
+                                       _ptr(dgamma_k), _ptr(dbeta_k), _ptr(dalpha), _ptr(ws), ws.numel(), _stream()),
                   "norm_act_bwd")
+        if sync is not None:
+            tot = sync.all_reduce(torch.cat([dbeta_k.double(), dgamma_k.double()]))
+            cnt = ctx.sync_count
+            gam = gamma.double() if gamma is not None else torch.ones(g.c, dtype=torch.float64, device=x.device)
+            a0 = (-gam * invstd.double() * tot[:g.c] / cnt).to(torch.float32).contiguous()
+            b1 = (-gam * invstd.double() ** 2 * tot[g.c:] / cnt).to(torch.float32).contiguous()
+            ones = torch.ones(g.c, dtype=torch.float32, device=x.device)
+            corr = _new(x.shape, x)
+            ga = NormGeom(g.n, g.vox, g.c, g.c, g.c, 0, ACT_NONE, 1, 0.0, 0.0, 0, g.dtype)
+            # corr = b1 * (x - mean) + a0, then dx += corr
+            check(L.mri3d_norm_act_fwd(ctypes.byref(ga), _ptr(x), _ptr(mean), _ptr(ones), _ptr(b1), _ptr(a0), None, _ptr(corr),
+                                       _stream()), "norm_act_fwd")
+            check(L.mri3d_add_channels(_ptr(dx), _ptr(corr), _ptr(dx), g.n * g.vox, g.c, g.c, g.c, g.c, g.dtype, _stream()),
+                  "add_channels")
         return (dx, _sink_done(pg, dgamma, sg), _sink_done(pb, dbeta, sb), _sink_done(pa, dalpha, sa), None, None, None, None,
                 None, None, None, None, None)
 

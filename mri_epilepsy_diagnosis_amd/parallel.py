@@ -64,6 +64,30 @@ class FlatParams:
         return 1.0
 
 
+class SyncBatchNorm:
+    """Synchronised BatchNorm statistics over the data-parallel ranks (SURVEY §8e "parity mode"; the default is local
+    statistics): inside `with parallel.SyncBatchNorm(group):` every training-mode BatchNorm3d of the HIP path sums its
+    (count, sum x, sum x^2) forward and (sum dy, sum dy*xhat) backward over the ranks, so world_size ranks x B volumes see the
+    statistics one device would see with world_size*B volumes.  Two float64 all-reduces of 2C(+1) numbers per layer and step."""
+
+    def __init__(self, group=None):
+        self.group = group
+        self._prev = None
+
+    def all_reduce(self, t):
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size(self.group) > 1:
+            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+        return t
+
+    def __enter__(self):
+        self._prev = ops.set_sync_batchnorm(self)
+        return self
+
+    def __exit__(self, *exc):
+        ops.set_sync_batchnorm(self._prev)
+        return False
+
+
 class FlatAdam:
     """Adam / AdamW over a FlatParams buffer in ONE HIP kernel (mri3d_adam_step).  Matches torch.optim.AdamW
     (decoupled=True; segmentation/routine.py:358) or torch.optim.Adam with L2 weight_decay (decoupled=False;

@@ -448,3 +448,91 @@ def test_flat_params_gradient_sinks_match_plain_autograd():
         ops.softmax_dice_loss(b(x), t).backward()
         for (name, pa), pb in zip(a.named_parameters(), b.parameters()):
             assert torch.equal(pa.grad, pb.grad), name
+
+
+class _OtherRank:
+    """Stands in for the second data-parallel rank of a synchronised BatchNorm: adds that rank's contribution (computed
+    analytically by the test) to each collective, in call order."""
+
+    def __init__(self, contributions):
+        self.contributions, self.calls = list(contributions), 0
+
+    def all_reduce(self, t):
+        out = t + self.contributions[self.calls].to(t)
+        self.calls += 1
+        return out
+
+
+@pytest.mark.parametrize("act", [None, "relu"])
+def test_sync_batchnorm_equals_the_global_batch(act):
+    """SURVEY §8e parity mode: one rank holding half of the batch, with the other half's sums arriving through the reducer,
+    must produce what a single device computes on the whole batch — outputs, input gradients, running statistics — and its
+    parameter gradients must be its share of the global ones."""
+    torch.manual_seed(3)
+    c, shape = 8, (6, 5, 7)
+    x = torch.randn(4, c, *shape) * 2.0 + 0.5
+    dy = torch.randn(4, c, *shape)
+    gamma, beta = torch.rand(c) + 0.5, torch.randn(c)
+
+    def run(xs, dys, reducer):
+        xd = xs.cuda().contiguous(memory_format=torch.channels_last_3d).requires_grad_(True)
+        g, b = gamma.cuda().requires_grad_(True), beta.cuda().requires_grad_(True)
+        rm, rv = torch.zeros(c, device="cuda"), torch.ones(c, device="cuda")
+        prev = ops.set_sync_batchnorm(reducer)
+        try:
+            y = ops.norm_act(xd, g, b, None, rm, rv, "sync" if reducer is not None else "batch", 0.1, 1e-5, act)
+            y.backward(dys.cuda().contiguous(memory_format=torch.channels_last_3d))
+        finally:
+            ops.set_sync_batchnorm(prev)
+        return y.detach().cpu(), xd.grad.cpu(), g.grad.cpu(), b.grad.cpu(), rm.cpu(), rv.cpu()
+
+    y_all, dx_all, dg_all, db_all, rm_all, rv_all = run(x, dy, None)
+    # the other rank's contributions, in float64 torch on the CPU
+    xb, dyb = x[2:].double(), dy[2:].double()
+    red = (0, 2, 3, 4)
+    cnt_b = torch.tensor([float(xb.numel() // c)], dtype=torch.float64)
+    fwd_b = torch.cat([cnt_b, xb.sum(red), (xb * xb).sum(red)])
+    n_all = x.numel() // c
+    mean = x.double().mean(red)
+    var = x.double().var(red, unbiased=False)
+    invstd = 1.0 / torch.sqrt(var + 1e-5)
+    xhat_b = (xb - mean.view(1, c, 1, 1, 1)) * invstd.view(1, c, 1, 1, 1)
+    z_b = xhat_b * gamma.double().view(1, c, 1, 1, 1) + beta.double().view(1, c, 1, 1, 1)
+    dyp_b = dyb * (z_b > 0) if act == "relu" else dyb
+    bwd_b = torch.cat([dyp_b.sum(red), (dyp_b * xhat_b).sum(red)])
+    reducer = _OtherRank([fwd_b, bwd_b])
+    y_a, dx_a, dg_a, db_a, rm_a, rv_a = run(x[:2], dy[:2], reducer)
+    assert reducer.calls == 2
+    assert torch.allclose(y_a, y_all[:2], rtol=1e-5, atol=1e-5)
+    assert torch.allclose(dx_a, dx_all[:2], rtol=1e-4, atol=2e-6)
+    assert torch.allclose(rm_a, rm_all, rtol=1e-5, atol=1e-6) and torch.allclose(rv_a, rv_all, rtol=1e-5, atol=1e-6)
+    # parameter gradients are per-rank sums: this rank's share + the other rank's share = the global gradient
+    assert torch.allclose(db_a.double() + bwd_b[:c], db_all.double(), rtol=1e-4, atol=1e-4)
+    assert torch.allclose(dg_a.double() + bwd_b[c:], dg_all.double(), rtol=1e-4, atol=1e-4)
+
+
+def test_sync_batchnorm_with_one_rank_is_local_batchnorm_and_reaches_the_modules():
+    """world_size 1: the reducer is the identity, so `with parallel.SyncBatchNorm():` must not change a U-Net step."""
+    torch.manual_seed(0)
+    x = torch.randn(2, 1, 16, 16, 16, device="cuda")
+    t = (torch.rand(2, 1, 16, 16, 16, device="cuda") < 0.3).float()
+    outs = []
+    for sync in (False, True):
+        torch.manual_seed(1)
+        m = UNet(in_channels=1, out_classes=2, dimensions=3, num_encoding_blocks=2, out_channels_first_layer=8,
+                 normalization="batch", upsampling_type="linear", padding=True, activation="PReLU").cuda().train()
+        if sync:
+            with parallel.SyncBatchNorm() as red:
+                assert ops.sync_batchnorm_reducer() is red
+                loss = ops.softmax_dice_loss(m(x), t)
+                loss.backward()
+            assert ops.sync_batchnorm_reducer() is None
+        else:
+            loss = ops.softmax_dice_loss(m(x), t)
+            loss.backward()
+        outs.append((loss.item(), [p.grad.clone() for p in m.parameters()], [b.clone() for b in m.buffers()]))
+    assert abs(outs[0][0] - outs[1][0]) < 1e-6
+    for ga, gb in zip(outs[0][1], outs[1][1]):
+        assert torch.allclose(ga, gb, rtol=2e-4, atol=1e-6)
+    for ba, bb in zip(outs[0][2], outs[1][2]):
+        assert torch.allclose(ba.float(), bb.float(), rtol=1e-5, atol=1e-6)
