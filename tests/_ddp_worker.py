@@ -35,6 +35,9 @@ if __name__ == "__main__":
     lo, hi = parallel.shard_range(world, rank, world)
     g = grads_for(range(lo, hi), reduce=True)
     torch.save(g, os.path.join(out, "grad_rank%d.pt" % rank))
+    # the collective behind parallel.SyncBatchNorm: a float64 sum over the ranks
+    packed = parallel.SyncBatchNorm().all_reduce(torch.full((5,), float(rank + 1), dtype=torch.float64))
+    assert packed.dtype == torch.float64 and torch.equal(packed, torch.full((5,), world * (world + 1) / 2.0, dtype=torch.float64))
     if rank == 0:
         torch.save(grads_for(range(world), reduce=False), os.path.join(out, "grad_single.pt"))
     dist.barrier()
