@@ -316,10 +316,7 @@ norm_act_bwd_reduce_kernel(const T* __restrict__ x, const T* __restrict__ dy, do
         }
         const T* xg = x + (int64_t)group * gvox * x_ld;
         const T* dg = dy + (int64_t)group * gvox * y_ld;
-        for (int64_t v = (int64_t)blockIdx.x * VT + vt; v < gvox; v += (int64_t)gridDim.x * VT) {
-            float xv[VEC], gv[VEC];
-            Ld<VEC>::load(xg + v * x_ld + c0, xv);
-            Ld<VEC>::load(dg + v * y_ld + c0, gv);
+        auto accumulate = [&](const float (&xv)[VEC], const float (&gv)[VEC]) {
 #pragma unroll
             for (int j = 0; j < VEC; ++j) {
                 float xh = (xv[j] - mu[j]) * is[j];
@@ -330,6 +327,24 @@ norm_act_bwd_reduce_kernel(const T* __restrict__ x, const T* __restrict__ dy, do
                 s1[j] = fma((double)du, (double)xh, s1[j]);
                 s2[j] += pos ? 0.0 : (double)gv[j] * (double)u;
             }
+        };
+        // two voxel rows per trip: four independent 16-byte loads in flight per lane, sums still in voxel order
+        const int64_t step = (int64_t)gridDim.x * VT;
+        int64_t v = (int64_t)blockIdx.x * VT + vt;
+        for (; v + step < gvox; v += 2 * step) {
+            float xa[VEC], ga[VEC], xb[VEC], gb[VEC];
+            Ld<VEC>::load(xg + v * x_ld + c0, xa);
+            Ld<VEC>::load(dg + v * y_ld + c0, ga);
+            Ld<VEC>::load(xg + (v + step) * x_ld + c0, xb);
+            Ld<VEC>::load(dg + (v + step) * y_ld + c0, gb);
+            accumulate(xa, ga);
+            accumulate(xb, gb);
+        }
+        for (; v < gvox; v += step) {
+            float xv[VEC], gv[VEC];
+            Ld<VEC>::load(xg + v * x_ld + c0, xv);
+            Ld<VEC>::load(dg + v * y_ld + c0, gv);
+            accumulate(xv, gv);
         }
     }
 #pragma unroll
@@ -471,10 +486,7 @@ norm_act_bwd_apply_kernel(const T* __restrict__ x, const T* __restrict__ dy, T* 
     const T* xg = x + (int64_t)group * gvox * x_ld;
     const T* dg = dy + (int64_t)group * gvox * y_ld;
     T* og = dx + (int64_t)group * gvox * x_ld;
-    for (int64_t v = (int64_t)blockIdx.x * VT + vt; v < gvox; v += (int64_t)gridDim.x * VT) {
-        float xv[VEC], gv[VEC], ov[VEC];
-        Ld<VEC>::load(xg + v * x_ld + c0, xv);
-        Ld<VEC>::load(dg + v * y_ld + c0, gv);
+    auto apply = [&](const float (&xv)[VEC], const float (&gv)[VEC], float (&ov)[VEC]) {
 #pragma unroll
         for (int j = 0; j < VEC; ++j) {
             float xh = (xv[j] - mu[j]) * is[j];
@@ -482,6 +494,26 @@ norm_act_bwd_apply_kernel(const T* __restrict__ x, const T* __restrict__ dy, T* 
             float du = (u > 0.f) ? gv[j] : gv[j] * al[j];
             ov[j] = fmaf(k0[j], du, -k1[j]) - xh * k2[j];
         }
+    };
+    // two voxel rows per trip: four independent 16-byte loads in flight per lane
+    const int64_t step = (int64_t)gridDim.x * VT;
+    int64_t v = (int64_t)blockIdx.x * VT + vt;
+    for (; v + step < gvox; v += 2 * step) {
+        float xa[VEC], ga[VEC], xb[VEC], gb[VEC], ov[VEC];
+        Ld<VEC>::load(xg + v * x_ld + c0, xa);
+        Ld<VEC>::load(dg + v * y_ld + c0, ga);
+        Ld<VEC>::load(xg + (v + step) * x_ld + c0, xb);
+        Ld<VEC>::load(dg + (v + step) * y_ld + c0, gb);
+        apply(xa, ga, ov);
+        Ld<VEC>::store(og + v * x_ld + c0, ov);
+        apply(xb, gb, ov);
+        Ld<VEC>::store(og + (v + step) * x_ld + c0, ov);
+    }
+    for (; v < gvox; v += step) {
+        float xv[VEC], gv[VEC], ov[VEC];
+        Ld<VEC>::load(xg + v * x_ld + c0, xv);
+        Ld<VEC>::load(dg + v * y_ld + c0, gv);
+        apply(xv, gv, ov);
         Ld<VEC>::store(og + v * x_ld + c0, ov);
     }
 }
