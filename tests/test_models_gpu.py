@@ -536,3 +536,26 @@ def test_sync_batchnorm_with_one_rank_is_local_batchnorm_and_reaches_the_modules
         assert torch.allclose(ga, gb, rtol=2e-4, atol=1e-6)
     for ba, bb in zip(outs[0][2], outs[1][2]):
         assert torch.allclose(ba.float(), bb.float(), rtol=1e-5, atol=1e-6)
+
+
+def test_two_ranks_on_one_gpu_with_sync_batchnorm_match_one_process_with_both_volumes(tmp_path):
+    """The data-parallel path on the real kernels: two processes (sharing this GPU, gloo for the collectives) each take one
+    volume, synchronise their BatchNorm statistics, all-reduce the flat gradient and step the fused AdamW — and end up with
+    the parameters, gradients and running statistics of ONE process that trained on both volumes as a batch of two."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = os.path.join(root, "tests", "_ddp_gpu_worker.py")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29541", PYTHONPATH=root)
+    procs = [subprocess.Popen([sys.executable, script, str(r), "2", str(tmp_path)], env=env) for r in range(2)]
+    for p in procs:
+        assert p.wait(timeout=600) == 0
+    r0, r1, one = (torch.load(tmp_path / n) for n in ("rank0.pt", "rank1.pt", "single.pt"))
+    assert torch.equal(r0["params"], r1["params"]) and torch.equal(r0["grads"], r1["grads"])     # replicas stay in lock-step
+    assert torch.allclose(r0["bufs"], one["bufs"], rtol=1e-5, atol=1e-6)                         # BatchNorm running statistics
+    gscale = one["grads"].abs().max().item()
+    assert (r0["grads"] - one["grads"]).abs().max().item() <= 2e-4 * gscale
+    # one AdamW step moves every parameter by ~lr in the direction of the gradient's sign: compare where the gradient is not tiny
+    big = one["grads"].abs() > 1e-3 * gscale
+    assert torch.allclose(r0["params"][big], one["params"][big], rtol=0, atol=2e-4)
