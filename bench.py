@@ -100,10 +100,14 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a ROCm device")
 
-    rank, local, world = parallel.init_from_env("nccl")
+    # MRI3D_BENCH_ONE_GPU_REHEARSAL=1: every rank uses cuda:0 and the collectives go through gloo, so that the N > 1 code path
+    # (barriers, max-over-ranks timing, the rank-0 JSON line) can be rehearsed on a one-GPU box; the value it prints is
+    # meaningless (the ranks time-slice one device).  Never set by the driver: real runs use one GPU per rank over RCCL.
+    rehearsal = os.environ.get("MRI3D_BENCH_ONE_GPU_REHEARSAL") == "1"
+    rank, local, world = parallel.init_from_env("gloo" if rehearsal else "nccl")
     if world != args.gpus and world > 1:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
-    device = torch.device("cuda", local)
+    device = torch.device("cuda", 0 if rehearsal else local)
     torch.cuda.set_device(device)
 
     model = build_model(device)

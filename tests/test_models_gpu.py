@@ -559,3 +559,26 @@ def test_two_ranks_on_one_gpu_with_sync_batchnorm_match_one_process_with_both_vo
     # one AdamW step moves every parameter by ~lr in the direction of the gradient's sign: compare where the gradient is not tiny
     big = one["grads"].abs() > 1e-3 * gscale
     assert torch.allclose(r0["params"][big], one["params"][big], rtol=0, atol=2e-4)
+
+
+def test_bench_multi_rank_path_rehearsed_on_one_gpu():
+    """`bench.py --gpus 2` as the driver launches it (torch.distributed.run, one process per rank), rehearsed on this one-GPU
+    box: both ranks share cuda:0 and gloo carries the collectives (MRI3D_BENCH_ONE_GPU_REHEARSAL).  Checks the contract of the
+    JSON line for N > 1 — exactly one line, from rank 0, whole-job aggregate, weak scaling — not its value."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MRI3D_BENCH_ONE_GPU_REHEARSAL="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29547", os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1"]
+    res = subprocess.run(cmd, env=env, cwd=root, capture_output=True, text=True, timeout=900)
+    assert res.returncode == 0, res.stderr[-2000:]
+    lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, res.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["steps"] == 2 and out["warmup"] == 1 and out["scaling"] == "weak"
+    assert out["config"]["global_batch"] == 4 and out["config"]["parallelism"] == "dp2"
+    assert out["value"] > 0 and abs(out["value"] - 4 * 2 / (out["ms_per_step"] * 2 / 1e3)) < 1e-2 * out["value"]
+    assert "cpu_baseline" not in out and out["roofline"]["frac"] > 0
