@@ -27,6 +27,9 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
+# the host driver of this pool only supports dmabuf IPC: without this RCCL's multi-process setup fails with
+# `hipIpcGetMemHandle: invalid argument` (normally already exported by the environment)
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 import torch  # noqa: E402
 
