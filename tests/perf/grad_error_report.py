@@ -1,8 +1,8 @@
 """Per-parameter gradient error of the HIP U-Net vs an fp64 CPU run, next to torch-CPU-fp32's error (diagnostic)."""
 import copy, os, sys
 import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
 from mri_epilepsy_diagnosis_amd import ops
 from mri_epilepsy_diagnosis_amd.unet import UNet
 from oracle import losses, unet_recon

@@ -1,7 +1,7 @@
 """Patch pipeline on one MI355X: cutting training batches of 16 x 64^3 windows out of HBM-resident
 subjects, and the grid inference of pretraining_3d_unet.ipynb cell 26 (36 windows of 64^3, overlap 4, U-Net c0=8, arg-max,
 aggregate) on a 160x192x160 volume; the numpy restatement of the same window copies is timed beside it on one host core.
-    python tools/patch_bench.py"""
+    python tests/perf/patch_bench.py"""
 import os
 import sys
 import time
@@ -9,7 +9,7 @@ import time
 import numpy as np
 import torch
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from mri_epilepsy_diagnosis_amd.segmentation import patches as P  # noqa: E402
 from mri_epilepsy_diagnosis_amd.unet import UNet  # noqa: E402

@@ -1,5 +1,5 @@
 """Histogram standardisation of one 160x192x160 volume: device path vs the numpy oracle on one host core (the reference's
-collate function runs it per sample on the CPU).   python tools/preprocess_bench.py"""
+collate function runs it per sample on the CPU).   python tests/perf/preprocess_bench.py"""
 import os
 import sys
 import time
@@ -7,7 +7,7 @@ import time
 import numpy as np
 import torch
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from mri_epilepsy_diagnosis_amd.classification import preprocessing as P  # noqa: E402
 from oracle import preprocessing as O_PRE  # noqa: E402

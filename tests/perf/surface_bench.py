@@ -1,5 +1,5 @@
 """Average surface distance of two 160x192x160 masks: device path vs the scipy oracle on one host core (the reference's
-validation spends 5-7 s per volume here, results_validation.ipynb:267).   python tools/surface_bench.py"""
+validation spends 5-7 s per volume here, results_validation.ipynb:267).   python tests/perf/surface_bench.py"""
 import os
 import sys
 import time
@@ -7,7 +7,7 @@ import time
 import numpy as np
 import torch
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from mri_epilepsy_diagnosis_amd.segmentation import surface  # noqa: E402
 from oracle import metrics as O_MET  # noqa: E402

@@ -68,12 +68,19 @@ def test_product_ops_refuse_cpu_tensors():
 
 
 def test_product_package_never_imports_oracle():
-    pkg = os.path.join(ROOT, "mri_epilepsy_diagnosis_amd")
-    for d, _, files in os.walk(pkg):
-        for f in files:
-            if f.endswith((".py", ".hip", ".h", ".cpp")):
-                src = open(os.path.join(d, f)).read()
-                assert "import oracle" not in src and "from oracle" not in src, os.path.join(d, f)
+    """The oracle is test infrastructure: only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline may touch it."""
+    for top in ("mri_epilepsy_diagnosis_amd", "tools", "include"):
+        for d, _, files in os.walk(os.path.join(ROOT, top)):
+            for f in files:
+                if f.endswith((".py", ".hip", ".h", ".cpp", ".sh")):
+                    src = open(os.path.join(d, f)).read()
+                    assert "import oracle" not in src and "from oracle" not in src, os.path.join(d, f)
+    # the two root scripts import it in exactly one function each
+    for name, func in (("bench.py", "def cpu_baseline"), ("__graft_entry__.py", "def smoke")):
+        src = open(os.path.join(ROOT, name)).read()
+        head, _, tail = src.partition(func)
+        assert "from oracle" not in head and "import oracle" not in head, name
+        assert "from oracle" in tail, name
 
 
 def test_prepare_batch_binarises_like_reference():
