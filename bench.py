@@ -31,8 +31,6 @@ if ROOT not in sys.path:
 # `hipIpcGetMemHandle: invalid argument` (normally already exported by the environment)
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
-import torch  # noqa: E402
-
 PEAK_F32_TFLOPS = 157.3  # MI355X dense fp32 (vector == fp32-input MFMA), MI355X_MICROARCH.md
 PEAK_BF16_TFLOPS = 2516.0  # MI355X dense bf16 MFMA
 PEAK_HBM_GBS = 8000.0    # HBM3E spec
@@ -42,6 +40,7 @@ C0 = 8
 
 
 def build_model(device):
+    import torch
     from mri_epilepsy_diagnosis_amd.unet import UNet
     torch.manual_seed(0)
     return UNet(in_channels=1, out_classes=2, dimensions=3, num_encoding_blocks=3, out_channels_first_layer=C0,
@@ -50,6 +49,7 @@ def build_model(device):
 
 def cpu_baseline(max_seconds=25.0):
     """Oracle (CPU restatement of the reference model) fwd+bwd+AdamW on batch-1 volumes of the bench size."""
+    import torch
     from oracle import losses, unet_recon
     torch.manual_seed(0)
     try:
@@ -84,6 +84,65 @@ def cpu_baseline(max_seconds=25.0):
                       "of 1x%dx%dx%d fp32, torch %s, %d threads" % (len(times), C0, *SHAPE, torch.__version__, threads)}
 
 
+def launch_ranks(n, argv):
+    """`python bench.py --gpus N` (N > 1) without a torchrun environment: this process becomes a pure launcher.  It has not
+    imported torch and never touches the GPU (no os.exec of a GPU process either): it starts
+    `python -m torch.distributed.run --nproc-per-node N bench.py <same arguments>` as a CHILD, one fresh process per rank,
+    relays rank 0's single JSON line, and exits non-zero if any rank failed or no line came back."""
+    import socket
+    import subprocess
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:     # a free rendezvous port on the loopback interface
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ, MRI3D_BENCH_LAUNCHED_BY_PARENT="1")
+    proc = subprocess.Popen(cmd, env=env, cwd=ROOT, stdout=subprocess.PIPE, text=True)
+    lines = []
+    for ln in proc.stdout:
+        if ln.startswith("{"):
+            lines.append(ln.strip())
+        else:
+            sys.stderr.write(ln)
+    rc = proc.wait()
+    if rc != 0:
+        raise SystemExit("bench.py: the %d-rank run failed (torch.distributed.run exit code %d)" % (n, rc))
+    if len(lines) != 1:
+        raise SystemExit("bench.py: expected ONE JSON line from rank 0 of the %d-rank run, got %d" % (n, len(lines)))
+    out = json.loads(lines[0])
+    if out.get("n_gpus") != n or out.get("ranks_seen") != n:
+        raise SystemExit("bench.py: asked for %d ranks, the run saw n_gpus=%r ranks_seen=%r"
+                         % (n, out.get("n_gpus"), out.get("ranks_seen")))
+    print(lines[0], flush=True)
+
+
+def launch_check(args):
+    """--launch-check: the N-rank plumbing only (rendezvous, barrier, MAX all-reduce, one JSON line from rank 0), no model
+    and no kernels — what the CPU suite can drive without a GPU (gloo).  Its line carries "launch_check": true and no value."""
+    import torch
+    import torch.distributed as dist
+    from mri_epilepsy_diagnosis_amd import parallel
+    backend = "nccl" if (torch.cuda.is_available() and os.environ.get("MRI3D_BENCH_ONE_GPU_REHEARSAL") != "1") else "gloo"
+    rank, local, world = parallel.init_from_env(backend)
+    if world != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    dev = torch.device("cuda", local) if backend == "nccl" else torch.device("cpu")
+    seen = torch.ones(1, device=dev, dtype=torch.float64)
+    tt = torch.tensor([float(rank + 1)], device=dev, dtype=torch.float64)
+    if world > 1:
+        dist.barrier()
+        dist.all_reduce(seen, op=dist.ReduceOp.SUM)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+    if rank == 0:
+        print(json.dumps({"launch_check": True, "metric": "MRI volumes/sec (fwd+bwd) 3D U-Net @160x192x160", "value": None,
+                          "n_gpus": world, "ranks_seen": dist.get_world_size() if world > 1 else 1,
+                          "ranks_counted_by_all_reduce": int(seen.item()), "max_over_ranks": tt.item(),
+                          "backend": backend if world > 1 else None}), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -92,24 +151,45 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--dtype", choices=("f32", "bf16"), default="f32")
     ap.add_argument("--graph", choices=("auto", "on", "off"), default="auto",
-                    help="replay forward+backward as one captured hipGraph.  auto = off for f32 (GPU-bound: 37.73 vs 37.65 "
-                         "ms/step measured, and the per-kernel events of the roofline object need eager launches inside the "
-                         "timed region), on for bf16 (host-bound when eager: 16.7 -> 13.4 ms/step)")
+                    help="replay forward+backward as one captured hipGraph.  auto = off for f32 (GPU-bound, and the "
+                         "per-kernel events of the roofline object need eager launches inside the timed region), on for "
+                         "bf16 (host-bound when eager)")
+    ap.add_argument("--launch-check", action="store_true",
+                    help="exercise only the N-rank launch / rendezvous / JSON-line plumbing (no model, no kernels)")
     args = ap.parse_args()
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
 
+    # N > 1 and no torchrun environment: become the launcher BEFORE torch is imported or any GPU call is made.
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return launch_ranks(args.gpus, sys.argv[1:])
+    env_world = int(os.environ.get("WORLD_SIZE", "1"))
+    if env_world != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d: start it as `python bench.py --gpus N` (self-launching) or as "
+                         "`python -m torch.distributed.run --nproc-per-node N bench.py --gpus N`" % (args.gpus, env_world))
+    if args.launch_check:
+        return launch_check(args)
+
+    import torch
     from mri_epilepsy_diagnosis_amd import _lib, ops, parallel
     if not os.path.exists(_lib.LIB_PATH):
         raise SystemExit("libmri3d_hip.so is missing — run `python __graft_entry__.py` first (no fallback path exists)")
+    # MRI3D_BENCH_ONE_GPU_REHEARSAL=1: every rank uses cuda:0 and the collectives go through gloo, so that the N > 1 code path
+    # (launcher, barriers, max-over-ranks timing, the rank-0 JSON line) can be rehearsed on a one-GPU box; the value it prints
+    # is meaningless (the ranks time-slice one device).  Never set by the driver: real runs use one GPU per rank over RCCL.
+    rehearsal = os.environ.get("MRI3D_BENCH_ONE_GPU_REHEARSAL") == "1"
+    # device_count() does not initialise the GPU: a rank never grabs a device that does not exist
+    if not rehearsal and torch.cuda.device_count() < args.gpus:
+        raise SystemExit("--gpus %d but only %d ROCm device(s) are visible" % (args.gpus, torch.cuda.device_count()))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a ROCm device")
 
-    # MRI3D_BENCH_ONE_GPU_REHEARSAL=1: every rank uses cuda:0 and the collectives go through gloo, so that the N > 1 code path
-    # (barriers, max-over-ranks timing, the rank-0 JSON line) can be rehearsed on a one-GPU box; the value it prints is
-    # meaningless (the ranks time-slice one device).  Never set by the driver: real runs use one GPU per rank over RCCL.
-    rehearsal = os.environ.get("MRI3D_BENCH_ONE_GPU_REHEARSAL") == "1"
-    rank, local, world = parallel.init_from_env("gloo" if rehearsal else "nccl")
-    if world != args.gpus and world > 1:
-        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    backend = "gloo" if rehearsal else "nccl"
+    rank, local, world = parallel.init_from_env(backend)
+    assert world == args.gpus
+    ranks_seen = torch.distributed.get_world_size() if world > 1 else 1
+    if ranks_seen != args.gpus:
+        raise SystemExit("--gpus %d but the process group has %d ranks" % (args.gpus, ranks_seen))
     device = torch.device("cuda", 0 if rehearsal else local)
     torch.cuda.set_device(device)
 
@@ -240,6 +320,8 @@ def main():
             "value": round(world * PER_GPU_BATCH * args.steps / elapsed, 4),
             "unit": "volumes/s",
             "n_gpus": world,
+            "ranks_seen": ranks_seen,
+            "backend": ("rccl(nccl)" if backend == "nccl" else backend) if world > 1 else None,
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 3),

@@ -180,3 +180,39 @@ def test_data_parallel_gloo_world2_matches_single_process(tmp_path):
     ref = torch.load(tmp_path / "grad_single.pt")
     assert torch.equal(g0, g1)
     np.testing.assert_allclose(g0.numpy(), ref.numpy(), rtol=1e-4, atol=1e-7)
+
+
+def _run_bench(argv, env_extra=None, drop=()):
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT") + tuple(drop)}
+    env.update(env_extra or {})
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + argv, env=env, cwd=ROOT, capture_output=True,
+                          text=True, timeout=600)
+
+
+def test_bench_gpus_n_launches_its_own_ranks():
+    """`python bench.py --gpus 2` with NO torchrun in the command and no WORLD_SIZE in the environment must itself start two
+    ranks (it used to run one GPU silently).  --launch-check runs the launcher, the rendezvous, a barrier and
+    two all-reduces over gloo and prints rank 0's line; no model or kernel is involved (there is no GPU here)."""
+    import json
+    res = _run_bench(["--gpus", "2", "--launch-check"])
+    assert res.returncode == 0, res.stderr[-2000:]
+    lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, res.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["ranks_seen"] == 2 and out["ranks_counted_by_all_reduce"] == 2
+    assert out["max_over_ranks"] == 2.0 and out["backend"] == "gloo" and out["launch_check"] is True
+
+
+def test_bench_refuses_a_world_size_that_is_not_gpus():
+    res = _run_bench(["--gpus", "2", "--launch-check"], env_extra={"WORLD_SIZE": "1"})
+    assert res.returncode != 0 and "WORLD_SIZE=1" in res.stderr and not res.stdout.strip()
+    res = _run_bench(["--gpus", "1", "--launch-check"], env_extra={"WORLD_SIZE": "2", "RANK": "0"})
+    assert res.returncode != 0 and "WORLD_SIZE=2" in res.stderr
+
+
+@pytest.mark.skipif(torch.cuda.is_available(), reason="checks the loud failure of the N-rank run on a box without GPUs")
+def test_bench_launcher_propagates_rank_failure():
+    """Without a GPU every rank of the real bench refuses to run; the launcher must exit non-zero and print no JSON line."""
+    res = _run_bench(["--gpus", "2", "--steps", "1", "--warmup", "0"])
+    assert res.returncode != 0 and not [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
+    assert "ROCm device" in res.stderr

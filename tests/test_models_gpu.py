@@ -582,3 +582,23 @@ def test_bench_multi_rank_path_rehearsed_on_one_gpu():
     assert out["config"]["global_batch"] == 4 and out["config"]["parallelism"] == "dp2"
     assert out["value"] > 0 and abs(out["value"] - 4 * 2 / (out["ms_per_step"] * 2 / 1e3)) < 1e-2 * out["value"]
     assert "cpu_baseline" not in out and out["roofline"]["frac"] > 0
+    assert out["ranks_seen"] == 2 and out["backend"] == "gloo"
+
+
+def test_bench_gpus_2_self_launches_two_ranks_on_one_gpu():
+    """The form the driver's N=1 run used — plain `python bench.py --gpus 2`, no torchrun, no WORLD_SIZE — must start its own
+    two ranks (a fresh child process per rank; the parent never touches the GPU) and report n_gpus == ranks_seen == 2."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["MRI3D_BENCH_ONE_GPU_REHEARSAL"] = "1"
+    res = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1"],
+                         env=env, cwd=root, capture_output=True, text=True, timeout=900)
+    assert res.returncode == 0, res.stderr[-2000:]
+    lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, res.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["ranks_seen"] == 2 and out["config"]["global_batch"] == 4 and out["value"] > 0
