@@ -53,14 +53,19 @@ def train(model, optimizer, scheduler, train_dataloader, val_dataloader, device,
     for epoch in range(max_epoch):
         start_time = time.time()
         tl, tp, tt = run_one_epoch(model, train_dataloader, criterion, True, device, optimizer, scheduler, experiment)
-        epoch_train_loss.append(np.mean(tl))
-        epoch_train_metric.append(metric(tt, tp))
         if val_dataloader is not None:
             with torch.no_grad():
                 vl, vp, vt = run_one_epoch(model, val_dataloader, criterion, False, device, optimizer, scheduler,
                                            experiment)
+        epoch_train_loss.append(np.mean(tl))
+        epoch_train_metric.append(metric(tt, tp))
+        if experiment:
+            experiment.log_metrics({"mean_train_loss": np.mean(tl), "train_metric": metric(tt, tp)}, epoch=epoch)
+        if val_dataloader is not None:
             epoch_val_loss.append(np.mean(vl))
             epoch_val_metric.append(metric(vt, vp))
+            if experiment:
+                experiment.log_metrics({"mean_val_loss": np.mean(vl), "val_metric": metric(vt, vp)}, epoch=epoch)
         if verbose:
             print("Epoch {} of {} took {:.3f}s".format(epoch + 1, max_epoch, time.time() - start_time))
             print("  training loss (in-iteration): \t{:.6f}".format(epoch_train_loss[-1]))

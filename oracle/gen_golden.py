@@ -240,6 +240,254 @@ def main():
     print("unet ok", traj)
 
 
+class InjectedDropout3d(torch.nn.Module):
+    """Dropout3d with the Bernoulli keep-masks supplied by the caller (one (N, C) mask per call, in call order), so that a
+    train-mode Modified3DUNet (Dropout3d(0.6), modified_3dunet.py:114-116) is comparable between implementations."""
+
+    def __init__(self, p, masks):
+        super().__init__()
+        self.p, self.masks, self.calls = p, masks, 0
+
+    def forward(self, x):
+        keep = self.masks[self.calls].to(x)
+        self.calls += 1
+        assert keep.shape == x.shape[:2]
+        return x * (keep / (1.0 - self.p)).view(*keep.shape, 1, 1, 1)
+
+
+def dropout_masks(seed, n, widths, p=0.6):
+    g = torch.Generator().manual_seed(seed)
+    return [(torch.rand(n, c, generator=g) >= p).float() for c in widths]
+
+
+def configs():
+    """Fixtures at BASELINE.json's own configuration sizes, recorded from the REFERENCE modules where they are
+    importable (cfg3: AE_model.py at batch 4 x 160x192x160; cfg5: cnn_model.CNN on 32^3 patches, batch 64 = the per-GPU share
+    of 512/8; Modified3DUNet in TRAIN mode with injected Dropout3d masks) and from oracle.unet_recon for `unet.UNet`
+    (third-party, absent) at 1 x 160x192x160 (cfg2's volume size)."""
+    sys.path.insert(0, os.path.join(REF, "classification", "models"))
+    sys.path.insert(0, os.path.join(REF, "segmentation", "models"))
+    import AE_model as R_AE          # noqa: E402
+    import cnn_model as R_CNN        # noqa: E402
+    import modified_3dunet as R_M    # noqa: E402
+    from oracle import ae_model as O_AE, cnn_model as O_CNN, modified_3dunet as O_M, unet_recon, losses
+    torch.set_num_threads(8)
+    full = (160, 192, 160)
+
+    # ---- cfg3a: full AE reconstruction (MSE) step, batch 4 x 160x192x160 (train_AE.ipynb cell 9's loss)
+    torch.manual_seed(0); ref = R_AE.AE(**AE_KWARGS_93_6_4)
+    torch.manual_seed(0); orc = O_AE.AE(**AE_KWARGS_93_6_4)
+    assert_same_state(ref, orc)
+    x = seeded_randn(131, (4, 1) + full)
+    np.savez(os.path.join(OUT, "cfg3_ae_mse_b4_160.npz"), **record(ref, orc, x, lambda o: F.mse_loss(o, x), train=True))
+    print("cfg3 AE ok")
+
+    # ---- cfg3b: encoder + classifier head CE step (head built with conv_pad=1, l_in=64*2*3*2=768: SURVEY §8d)
+    ckw = dict(CLF_KWARGS, conv_pad=1, l_in=768, p_drop=0.0)     # dropout off: deterministic comparison
+    y = torch.tensor([0, 1, 1, 0])
+    res = []
+    for A in (R_AE, O_AE):
+        torch.manual_seed(0)
+        enc, clf = A.AE(**AE_KWARGS_93_6_4).enc, A.Classificator(**ckw)
+        enc.train(); clf.train()
+        lat, sizes = enc(x)
+        logits = clf(lat)
+        loss = F.cross_entropy(logits, y)
+        loss.backward()
+        res.append((lat.detach(), logits.detach(), loss.detach(), grad_norms(enc), grad_norms(clf), sizes, enc, clf))
+    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1]) and torch.equal(res[0][2], res[1][2])
+    assert np.array_equal(res[0][3], res[1][3]) and np.array_equal(res[0][4], res[1][4]) and res[0][5] == res[1][5]
+    assert tuple(res[0][0].shape) == (4, 32, 2, 3, 2)
+    bn = res[0][6].blocks[0].block["5_batch_norm"] if hasattr(res[0][6], "blocks") else None
+    np.savez(os.path.join(OUT, "cfg3_enc_clf_ce_b4_160.npz"), latent=res[0][0].numpy(), logits=res[0][1].numpy(),
+             loss=np.array(res[0][2].item()), grad_norms_enc=res[0][3], grad_norms_clf=res[0][4],
+             sizes=np.array([list(s_) for s_ in res[0][5]]))
+    print("cfg3 enc+clf ok", res[0][1])
+
+    # ---- cfg5: CNN(32^3) + Linear(128, 2), batch 64 (per-GPU share of 512 over 8 GPUs), CE
+    torch.manual_seed(0); ref = torch.nn.Sequential(R_CNN.CNN(input_shape=(32, 32, 32), n_filters=16, n_blocks=3), torch.nn.Linear(128, 2))
+    torch.manual_seed(0); orc = torch.nn.Sequential(O_CNN.CNN(input_shape=(32, 32, 32), n_filters=16, n_blocks=3), torch.nn.Linear(128, 2))
+    assert_same_state(ref, orc)
+    xp = seeded_randn(151, (64, 1, 32, 32, 32))
+    yp = torch.arange(64) % 2
+    np.savez(os.path.join(OUT, "cfg5_cnn_b64_32.npz"), **record(ref, orc, xp, lambda o: F.cross_entropy(o, yp), train=True))
+    print("cfg5 ok")
+
+    # ---- a10 in TRAIN mode: Dropout3d(0.6) masks injected (5 calls, widths 8, 16, 32, 64, 128)
+    masks = dropout_masks(171, 2, [8, 16, 32, 64, 128])
+    torch.manual_seed(0); ref = R_M.Modified3DUNet(1, 2, 8)
+    torch.manual_seed(0); orc = O_M.Modified3DUNet(1, 2, 8)
+    assert_same_state(ref, orc)
+    ref.dropout3d = InjectedDropout3d(0.6, masks)
+    orc.dropout3d = InjectedDropout3d(0.6, masks)
+    xm = seeded_randn(172, (2, 1, 48, 32, 32))
+    tm = (seeded_rand(173, (2, 1, 48, 32, 32)) < 0.2).float()
+    ref.train(); orc.train()
+    rec = []
+    for m in (ref, orc):
+        m.dropout3d.calls = 0
+        m.zero_grad(set_to_none=True)
+        out = m(xm)
+        loss = losses.softmax_dice_loss(out, tm)
+        loss.backward()
+        assert m.dropout3d.calls == 5
+        rec.append((out.detach(), loss.detach(), grad_norms(m)))
+    assert torch.equal(rec[0][0], rec[1][0]) and torch.equal(rec[0][1], rec[1][1]) and np.array_equal(rec[0][2], rec[1][2])
+    smp, stride = sample(rec[0][0])
+    np.savez(os.path.join(OUT, "modified3dunet_train_b8_48.npz"), out_sample=smp, out_stride=np.array(stride),
+             loss=np.array(rec[0][1].item()), grad_norms=rec[0][2])
+    print("modified3dunet train-mode ok")
+
+    # ---- cfg2 volume size: unet.UNet c0=8 (oracle.unet_recon; upstream package absent) with the shipped checkpoint,
+    #      eval mask + one train step on 1 x 160x192x160
+    m = unet_recon.UNetRecon(out_channels_first_layer=8)
+    m.load_state_dict(torch.load(os.path.join(OUT, "ckpt", "whole_im_train_seg_parc_epoch_7.pth"), weights_only=True, map_location="cpu"))
+    xu = seeded_randn(161, (1, 1) + full)
+    tu = (seeded_rand(162, (1, 1) + full) < 0.1).float()
+    m.eval()
+    with torch.no_grad():
+        lo = m(xu)
+    mask = lo.argmax(dim=1).to(torch.uint8).numpy()
+    margin = (lo[:, 1] - lo[:, 0]).abs()
+    d = dict(eval_sample=sample(lo)[0], eval_stride=np.array(sample(lo)[1]), mask_sha256=np.array(hashlib.sha256(mask.tobytes()).hexdigest()),
+             mask_sum=np.array(int(mask.sum())), min_margin=np.array(margin.min().item()),
+             n_margin_below_1e4=np.array(int((margin < 1e-4 * lo.abs().max()).sum())))
+    m.train(); m.zero_grad()
+    lo = m(xu)
+    loss = losses.softmax_dice_loss(lo, tu)
+    loss.backward()
+    d.update(train_sample=sample(lo)[0], loss=np.array(loss.item()), grad_norms=grad_norms(m))
+    np.savez(os.path.join(OUT, "unet_c8_ckpt_160x192x160.npz"), **d)
+    print("unet full size ok", loss.item(), d["mask_sum"], d["min_margin"], d["n_margin_below_1e4"])
+
+
+def _ref_clf_routine():
+    """run_one_epoch / train / create_model_opt of the REFERENCE's classification/routine.py (:15-52, :55-159, :253-279),
+    extracted with `ast` and executed without importing the module (its top-level imports comet_ml / IPython are absent here;
+    with verbose=0 neither is touched)."""
+    import ast
+    import time
+    from tqdm import tqdm
+    src = open(os.path.join(REF, "classification", "routine.py")).read()
+    want = ("run_one_epoch", "train", "create_model_opt")
+    fns = [n for n in ast.parse(src).body if isinstance(n, ast.FunctionDef) and n.name in want]
+    assert [f.name for f in fns] == list(want)
+    ns = {"np": np, "torch": torch, "nn": torch.nn, "F": F, "time": time, "tqdm": tqdm}
+    exec(compile(ast.Module(body=fns, type_ignores=[]), "classification_routine_extract", "exec"), ns)
+    return ns
+
+
+class RecordingExperiment:
+    """A caller-supplied `experiment` object (the reference passes a comet_ml Experiment): records the calls."""
+
+    def __init__(self):
+        self.calls = []
+
+    def log_metric(self, name, value):
+        self.calls.append((name, float(value)))
+
+    def log_metrics(self, d, epoch=None):
+        for k in sorted(d):
+            self.calls.append(("%s@%s" % (k, epoch), float(d[k])))
+
+
+def clf_loaders(seed, n_batches, batch, flip=False):
+    """Seeded (data, target, index) batches of 1x4x4x4 'volumes' whose label is the sign of the mean (learnable by a linear head)."""
+    g = torch.Generator().manual_seed(seed)
+    out = []
+    for b in range(n_batches):
+        x = torch.randn(batch, 1, 4, 4, 4, generator=g)
+        y = (x.mean(dim=(1, 2, 3, 4)) > 0).long()
+        if flip:
+            y = 1 - y
+        out.append((x, y, torch.arange(batch) + b * batch))
+    return out
+
+
+def clf_tiny_model():
+    torch.manual_seed(0)
+    return torch.nn.Sequential(torch.nn.Flatten(), torch.nn.Linear(64, 2))
+
+
+def accuracy(targets, probs):
+    return float(np.mean((np.asarray(probs) > 0.5) == (np.asarray(targets) == 1)))
+
+
+def clf_routine():
+    """tests/golden/clf_routine.npz: the REFERENCE's train / run_one_epoch on a tiny seeded CPU model (the loops are
+    model-agnostic host logic), incl. its per-batch scheduler.step(loss), early stopping, save cadence and the `patience_`
+    defect; create_model_opt(transfer=True) on the reference VoxResNet."""
+    import tempfile
+    ns = _ref_clf_routine()
+    rec = {}
+    # A: validation metric improves in epoch 0 (so the reference's `patience_` gets bound), then early-stops on patience
+    for tag, kw in (("A", dict(max_epoch=8, max_patience=2, eps=3e-3)), ("E", dict(max_epoch=8, max_patience=50, eps=0.62))):
+        m = clf_tiny_model()
+        opt = torch.optim.Adam(m.parameters(), 5e-2, weight_decay=0.01)
+        sch = torch.optim.lr_scheduler.ReduceLROnPlateau(opt, mode="min", factor=0.5, patience=2, threshold=0.001)
+        ex = RecordingExperiment()
+        with tempfile.TemporaryDirectory() as td:
+            path = os.path.join(td, "m.pth")
+            ret = ns["train"](m, opt, sch, clf_loaders(1, 4, 8), clf_loaders(2, 2, 8), "cpu", accuracy, verbose=0,
+                              model_save_path=path, experiment=ex, **kw)
+            saved = torch.load(path, weights_only=True)
+        rec[tag + "_ret"] = np.array([np.nan if v is None else float(v) for v in ret])
+        rec[tag + "_log_names"] = np.array([c[0] for c in ex.calls])
+        rec[tag + "_log_values"] = np.array([c[1] for c in ex.calls])
+        rec[tag + "_lr"] = np.array(opt.param_groups[0]["lr"])
+        rec[tag + "_params"] = torch.cat([p.detach().flatten() for p in m.parameters()]).numpy()
+        rec[tag + "_saved"] = torch.cat([v.flatten() for v in saved.values()]).numpy()
+        print("clf_routine", tag, ret, "lr", opt.param_groups[0]["lr"], "log calls", len(ex.calls))
+    # B: epoch-0 validation metric is 0 (labels flipped => never "improves" on best_metric=0): the reference raises
+    # UnboundLocalError on `patience_ += 1`;  C: no validation loader: raises at `if patience_ >= max_patience`
+    for tag, val in (("B", clf_loaders(3, 1, 8, flip=True)), ("C", None)):
+        m = clf_tiny_model()
+        with torch.no_grad():                       # make the model confidently right on unflipped labels
+            m[1].weight.copy_(torch.stack([-torch.ones(64), torch.ones(64)]))
+            m[1].bias.zero_()
+        opt = torch.optim.Adam(m.parameters(), 1e-5)
+        sch = torch.optim.lr_scheduler.ReduceLROnPlateau(opt, mode="min", factor=0.5, patience=2, threshold=0.001)
+        try:
+            ns["train"](m, opt, sch, clf_loaders(1, 2, 8), val, "cpu", accuracy, verbose=0, max_epoch=3, max_patience=2)
+            raised = "none"
+        except UnboundLocalError as e:
+            raised = "UnboundLocalError:" + str(e)
+        rec[tag + "_raised"] = np.array(raised)
+        print("clf_routine", tag, raised)
+    # run_one_epoch alone (train=True): per-batch scheduler.step(loss) — lr after 12 batches of a non-improving loss
+    m = clf_tiny_model()
+    opt = torch.optim.SGD(m.parameters(), 1e-3)
+    sch = torch.optim.lr_scheduler.ReduceLROnPlateau(opt, mode="min", factor=0.5, patience=2, threshold=0.001)
+    same = clf_loaders(5, 1, 8) * 12
+    losses_, probs, targets = ns["run_one_epoch"](m, same, torch.nn.CrossEntropyLoss(), True, "cpu", opt, sch, False)
+    rec["R_losses"] = np.array([float(v) for v in losses_])
+    rec["R_probs"] = np.array(probs)
+    rec["R_targets"] = np.array(targets)
+    rec["R_lr"] = np.array(opt.param_groups[0]["lr"])
+    rec["R_sched_num_bad"] = np.array(sch.num_bad_epochs)
+    rec["R_sched_last_epoch"] = np.array(sch.last_epoch)
+    print("run_one_epoch lr", opt.param_groups[0]["lr"], "scheduler steps", sch.last_epoch)
+    # create_model_opt(transfer=True) on the reference VoxResNet (cnn_model.py:43-101)
+    sys.path.insert(0, os.path.join(REF, "classification", "models"))
+    import cnn_model as R_CNN        # noqa: E402
+    torch.manual_seed(0)
+    base = R_CNN.VoxResNet(input_shape=(32, 32, 32), n_filters=8, n_blocks=3)
+    n_all = sum(p.numel() for p in base.parameters())
+    model, opt, sch = ns["create_model_opt"](base, transfer=True, lr=1e-5, patience=2)
+    model.eval()
+    with torch.no_grad():
+        out = model(seeded_randn(181, (2, 1, 32, 32, 32)))
+    last = list(list(model.children())[0].children())[-1]
+    rec.update(T_out=out.numpy(), T_last_weight=last.weight.detach().numpy(), T_last_bias=last.bias.detach().numpy(),
+               T_n_trainable=np.array(sum(p.numel() for p in model.parameters() if p.requires_grad)),
+               T_n_params=np.array(sum(p.numel() for p in model.parameters())), T_n_base=np.array(n_all),
+               T_opt_numel=np.array(sum(p.numel() for g_ in opt.param_groups for p in g_["params"])),
+               T_opt=np.array([opt.defaults["lr"], opt.defaults["weight_decay"], sch.factor, sch.patience, sch.threshold]),
+               T_names=np.array([k for k, _ in list(model.children())[0].named_children()]))
+    print("create_model_opt transfer ok", out)
+    np.savez(os.path.join(OUT, "clf_routine.npz"), **rec)
+
+
 def mask_metrics():
     """tests/golden/mask_metrics.npz: compute_dice_coefficient (segmentation/metrics.py:312-329) and get_iou_score
     (segmentation/routine.py:198-203) of the REFERENCE on seeded masks; the oracle restatement must agree exactly."""
@@ -379,8 +627,14 @@ if __name__ == "__main__":
         mask_metrics()
     elif len(sys.argv) > 1 and sys.argv[1] == "hist_std":
         hist_std()
+    elif len(sys.argv) > 1 and sys.argv[1] == "configs":
+        configs()
+    elif len(sys.argv) > 1 and sys.argv[1] == "clf_routine":
+        clf_routine()
     else:
         main()
         mask_metrics()
         hist_std()
         surface_asd()
+        configs()
+        clf_routine()
