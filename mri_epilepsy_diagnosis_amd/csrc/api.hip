@@ -41,6 +41,12 @@ int conv_pointwise_dgrad(const Mri3dConvGeom& g, const void* dy, const float* w,
 int conv_pointwise_wgrad(const Mri3dConvGeom& g, const void* x, const void* dy, float* dw, float* dbias, void* ws,
                          size_t ws_bytes, hipStream_t s);
 
+// the MFMA kernels move 16-byte pieces: a pitched channel slice whose base is not 16-byte aligned (legal for the generic
+// kernels) must not be routed to them
+static inline bool aligned16(const void* a, const void* b = nullptr, const void* c = nullptr) {
+    return ((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(b) | reinterpret_cast<uintptr_t>(c)) & 15) == 0;
+}
+
 static int conv_check(const Mri3dConvGeom* g, const char* who) {
     MRI3D_REQUIRE(g != nullptr, MRI3D_EINVAL, "%s: null geometry", who);
     MRI3D_REQUIRE(g->dtype == MRI3D_F32 || g->dtype == MRI3D_BF16, MRI3D_ENOTSUP, "%s: unknown dtype %d", who, g->dtype);
@@ -83,7 +89,7 @@ extern "C" int mri3d_conv3d_fwd(const Mri3dConvGeom* g, const void* x, const voi
     if (rc) return rc;
     MRI3D_REQUIRE(x && w && y, MRI3D_EINVAL, "conv3d_fwd: null pointer");
     hipStream_t s = static_cast<hipStream_t>(stream);
-    if (conv_mfma_supported(*g, MRI3D_PASS_FWD))
+    if (conv_mfma_supported(*g, MRI3D_PASS_FWD) && aligned16(x, y, workspace))
         return conv_mfma_fwd(*g, x, (const float*)w, (const float*)bias, y, workspace, ws_bytes, s);
     return conv_generic_fwd(*g, x, (const float*)w, (const float*)bias, y, workspace, ws_bytes, s);
 }
@@ -96,7 +102,7 @@ extern "C" int mri3d_conv3d_dgrad(const Mri3dConvGeom* g, const void* dy, const 
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (conv_pointwise_supported(*g, MRI3D_PASS_DGRAD) && aligned_vec4(g->dtype, dx))
         return conv_pointwise_dgrad(*g, dy, (const float*)w, (const float*)bias, dx, s);
-    if (conv_mfma_supported(*g, MRI3D_PASS_DGRAD))
+    if (conv_mfma_supported(*g, MRI3D_PASS_DGRAD) && aligned16(dy, dx, workspace))
         return conv_mfma_dgrad(*g, dy, (const float*)w, (const float*)bias, dx, workspace, ws_bytes, s);
     return conv_generic_dgrad(*g, dy, (const float*)w, (const float*)bias, dx, workspace, ws_bytes, s);
 }
@@ -109,7 +115,7 @@ extern "C" int mri3d_conv3d_wgrad(const Mri3dConvGeom* g, const void* x, const v
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (conv_pointwise_supported(*g, MRI3D_PASS_WGRAD) && aligned_vec4(g->dtype, x))
         return conv_pointwise_wgrad(*g, x, dy, (float*)dw, (float*)dbias, workspace, ws_bytes, s);
-    if (conv_mfma_supported(*g, MRI3D_PASS_WGRAD))
+    if (conv_mfma_supported(*g, MRI3D_PASS_WGRAD) && aligned16(x, dy, workspace))
         return conv_mfma_wgrad(*g, x, dy, (float*)dw, (float*)dbias, workspace, ws_bytes, s);
     return conv_generic_wgrad(*g, x, dy, (float*)dw, (float*)dbias, workspace, ws_bytes, s);
 }

@@ -4,6 +4,7 @@
 #include <stdint.h>
 #include <stdio.h>
 #include <stdarg.h>
+#include <stdlib.h>
 #include "../../include/mri3d.h"
 
 namespace mri3d {
@@ -26,6 +27,17 @@ inline int check_launch(const char* what) {
             return (code);                  \
         }                                   \
     } while (0)
+
+// A/B switches exist only in a tuning build (-DMRI3D_TUNING, tools/): the shipped library reads no environment variable, so a
+// stray variable in a job's environment cannot change which kernel runs or what it computes.
+#ifdef MRI3D_TUNING
+inline int tuning_knob(const char* name, int dflt) {
+    const char* v = getenv(name);
+    return v ? atoi(v) : dflt;
+}
+#else
+constexpr int tuning_knob(const char*, int dflt) { return dflt; }
+#endif
 
 inline int64_t cdiv64(int64_t a, int64_t b) { return (a + b - 1) / b; }
 inline int cdiv(int a, int b) { return (a + b - 1) / b; }

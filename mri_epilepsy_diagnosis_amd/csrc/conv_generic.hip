@@ -519,7 +519,7 @@ conv_wgrad_co1_kernel(Mri3dConvGeom g, const T* __restrict__ x, const T* __restr
 constexpr int kCo1Blocks = 1024;
 
 static bool wgrad_co1_ok(const Mri3dConvGeom& g) {
-    static const int off = getenv("MRI3D_CO1_OFF") ? atoi(getenv("MRI3D_CO1_OFF")) : 0;   // tuning aid (A/B)
+    static const int off = tuning_knob("MRI3D_CO1_OFF", 0);   // tuning aid (A/B)
     return !off && g.co == 1 && g.kd * g.kh * g.kw <= kSmTaps && (g.ci == 1 || ((g.ci == 4 || g.ci == 8 || g.ci == 16) && g.x_ld % 4 == 0)) &&
            (int64_t)g.dout * g.ho * g.wo < 0x7fffffffLL;
 }
@@ -858,7 +858,7 @@ conv_c1c1_wgrad_kernel(Mri3dConvGeom g, const T* __restrict__ x, const T* __rest
 constexpr int kC1C1Blocks = 1024;
 
 static bool c1c1_ok(const Mri3dConvGeom& g) {
-    static const int off = getenv("MRI3D_C1C1_OFF") ? atoi(getenv("MRI3D_C1C1_OFF")) : 0;   // tuning aid (A/B)
+    static const int off = tuning_knob("MRI3D_C1C1_OFF", 0);   // tuning aid (A/B)
     return !off && g.ci == 1 && g.co == 1 && g.kd == 3 && g.kh == 3 && g.kw == 3 && g.sd == 1 && g.sh == 1 && g.sw == 1 &&
            g.dd == 1 && g.dh == 1 && g.dw == 1 && g.pd == 1 && g.ph == 1 && g.pw == 1 &&
            (int64_t)g.n * cdiv(g.dout, C1D) * cdiv(g.ho, C1H) * cdiv(g.wo, C1WQ * 4) < 0x7fffffffLL;
@@ -873,7 +873,7 @@ static void launch_c1c1_stencil(const Mri3dConvGeom& g, const T* src, int src_ld
                        dst, dst_ld, tilesD, tilesH, tilesW, ntiles);
 }
 
-static const int g_cin1_off = getenv("MRI3D_CIN1_OFF") ? atoi(getenv("MRI3D_CIN1_OFF")) : 0;   // tuning aid (A/B)
+static const int g_cin1_off = tuning_knob("MRI3D_CIN1_OFF", 0);   // tuning aid (A/B)
 constexpr int kCin1Shares = 256;   // 3 * 256 = 768 workgroups = 3 per CU
 
 static bool cin1_ok(const Mri3dConvGeom& g) {

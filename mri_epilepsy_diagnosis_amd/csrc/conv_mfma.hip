@@ -109,136 +109,11 @@ __global__ void pack_w_mfma_bf16_kernel(const float* __restrict__ w, bf16_t* __r
     }
 }
 
-// ------------------------------------------------------------------ forward / dgrad kernel, version 1
-template <int NT, int CK>
-__global__ void __launch_bounds__(256, 2)
-conv_mfma_fwd_kernel(const float* __restrict__ x, const float* __restrict__ wp, const float* __restrict__ bias,
-                     float* __restrict__ y, int N, int D, int H, int W, int Kc, int x_ld, int Nc, int y_ld, int NTT,
-                     int tilesD, int tilesH, int tilesW, int ntiles, int ablate) {
-    constexpr int CP = CK;  // LDS voxel pitch in floats
-    constexpr int TG = tap_groups(CK);
-    constexpr int Q = CK / 4;
-    extern __shared__ __attribute__((aligned(16))) float lds[];
-
-    int tile = xcd_remap(blockIdx.x, ntiles);
-    const int tw = tile % tilesW;
-    tile /= tilesW;
-    const int th = tile % tilesH;
-    tile /= tilesH;
-    const int td = tile % tilesD;
-    const int n = tile / tilesD;
-    const int w0 = tw * TW, h0 = th * TH, d0 = td * TD;
-    const int nt0 = blockIdx.y * NT;
-
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int li = lane & 15, kq = lane >> 4;
-
-    f32x4 acc[TH][NT];
-#pragma unroll
-    for (int m = 0; m < TH; ++m)
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) acc[m][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-    const int nchunks = Kc / CK;
-    const float* xn = x + (int64_t)n * D * H * W * x_ld;
-    for (int ch = 0; ch < nchunks; ++ch) {
-        __syncthreads();
-        if (!(ablate & 1))
-        for (int idx = tid; idx < HVOX * Q; idx += 256) {
-            const int q = idx % Q, v = idx / Q;
-            const int wx = v % HW;
-            const int t2 = v / HW;
-            const int hy = t2 % HH, dz = t2 / HH;
-            const int gd = d0 - 1 + dz, gh = h0 - 1 + hy, gw = w0 - 1 + wx;
-            float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
-            if ((unsigned)gd < (unsigned)D && (unsigned)gh < (unsigned)H && (unsigned)gw < (unsigned)W)
-                val = *reinterpret_cast<const float4*>(xn + (((int64_t)gd * H + gh) * W + gw) * x_ld + ch * CK + 4 * q);
-            *reinterpret_cast<float4*>(lds + v * CP + 4 * q) = val;
-        }
-        __syncthreads();
-
-        // Software pipeline over the tap groups: B fragments (global, L1/L2-resident packed weights) are fetched two
-        // tap groups ahead into a 3-deep register ring, A fragments (LDS) one tap group ahead into a 2-deep ring, so
-        // neither latency sits in front of an MFMA.
-        if (ablate & 2) continue;
-        const float* wt = wp + ((size_t)ch * TG * NTT + nt0) * 256 + lane * 4;
-        const size_t wstep = (size_t)NTT * 256;
-        f32x4 bq[3][NT];
-        f32x4 aq[2][TH];
-        auto a_off = [&](int tg) -> int {
-            if (CK == 16) {
-                const int kd = tg / 9, kh = (tg / 3) % 3, kw = tg % 3;
-                return (((wv + kd) * HH + kh) * HW + (li + kw)) * CP + 4 * kq;
-            } else {
-                const int ta = pair_tap(tg, 0), tb = pair_tap(tg, 1) < 27 ? pair_tap(tg, 1) : 26;  // tap 27 has zero weights
-                const int oa = ((ta / 9) * HH + (ta / 3) % 3) * HW + ta % 3;
-                const int ob = ((tb / 9) * HH + (tb / 3) % 3) * HW + tb % 3;
-                return ((wv * HH) * HW + li + ((kq >> 1) ? ob : oa)) * CP + 4 * (kq & 1);
-            }
-        };
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) {
-            bq[0][nt] = *reinterpret_cast<const f32x4*>(wt + nt * 256);
-            bq[1][nt] = *reinterpret_cast<const f32x4*>(wt + wstep + nt * 256);
-        }
-        {
-            const int o0 = a_off(0);
-#pragma unroll
-            for (int m = 0; m < TH; ++m) aq[0][m] = *reinterpret_cast<const f32x4*>(lds + o0 + m * HW * CP);
-        }
-#pragma unroll
-        for (int tg = 0; tg < TG; ++tg) {
-            const int cur = tg % 3, nxt2 = (tg + 2) % 3, ac = tg & 1, an = (tg + 1) & 1;
-            if (tg + 2 < TG) {
-#pragma unroll
-                for (int nt = 0; nt < NT; ++nt)
-                    bq[nxt2][nt] = *reinterpret_cast<const f32x4*>(wt + (size_t)(tg + 2) * wstep + nt * 256);
-            }
-            if (tg + 1 < TG) {
-                const int o1 = a_off(tg + 1);
-#pragma unroll
-                for (int m = 0; m < TH; ++m) aq[an][m] = *reinterpret_cast<const f32x4*>(lds + o1 + m * HW * CP);
-            }
-            // keep the prefetches ABOVE this tap group's MFMAs (hipcc otherwise sinks them next to their first use)
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int s = 0; s < 4; ++s)
-#pragma unroll
-                for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-                    for (int m = 0; m < TH; ++m)
-                        acc[m][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(aq[ac][m][s], bq[cur][nt][s], acc[m][nt], 0, 0, 0);
-        }
-    }
-
-    // epilogue: lane holds rows (voxels) 4*kq + r, column (channel) li of every 16x16 tile
-    const int od = d0 + wv;
-    if (od < D && !(ablate & 4)) {
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) {
-            const int co = (nt0 + nt) * 16 + li;
-            if (co >= Nc) continue;
-            const float bv = bias ? bias[co] : 0.f;
-#pragma unroll
-            for (int m = 0; m < TH; ++m) {
-                const int oh = h0 + m;
-                if (oh >= H) continue;
-                float* yrow = y + ((((int64_t)n * D + od) * H + oh) * W) * y_ld + co;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int ow = w0 + 4 * kq + r;
-                    if (ow < W) yrow[(int64_t)ow * y_ld] = acc[m][nt][r] + bv;
-                }
-            }
-        }
-    }
-}
-
-// ------------------------------------------------------------------ forward / dgrad kernel, version 2
+// ------------------------------------------------------------------ forward / dgrad kernel
 // Persistent workgroups + double-buffered LDS + staging folded into the tap loop.
-//   v1 (above) alternates "stage a chunk" and "27 tap groups of MFMA" with a barrier pair in between; the two
-//   workgroups resident on a CU run in lock-step, so the staging time (1.0 of 4.1 ms on the 48->16 layer, measured by
-//   ablation) is NOT hidden.  v2 makes each workgroup self-overlapping:
+//   A first version (round 1, removed) alternated "stage a chunk" and "27 tap groups of MFMA" with a barrier pair in between; the two
+//   workgroups resident on a CU ran in lock-step, so the staging time (1.0 of 4.1 ms on the 48->16 layer, measured by
+//   ablation) was NOT hidden.  This kernel makes each workgroup self-overlapping:
 //     * K is consumed in 8-channel chunks (two taps share an MFMA k-step: 14 tap groups per chunk), so TWO halo tiles
 //       fit in LDS (2 x 34.5 KB) with two workgroups per CU;
 //     * while chunk i is multiplied out of buffer i&1, every lane also fetches its 9 16-byte pieces of chunk i+1 (of the
@@ -534,7 +409,7 @@ conv_mfma_fwd2_kernel(const T* __restrict__ x, const float* __restrict__ wp, con
 
 // ------------------------------------------------------------------ host side
 struct MfmaFwdPlan {
-    int CK, NT, NTT, gy, nchunks, tilesD, tilesH, tilesW, ntiles, v2, grid;
+    int CK, NT, NTT, gy, nchunks, tilesD, tilesH, tilesW, ntiles, grid;
     size_t wp_floats, smem;
 };
 
@@ -547,15 +422,11 @@ static bool mfma_fwd_plan(const Mri3dConvGeom& g, bool dgrad, MfmaFwdPlan& p) {
     const int in_ld = dgrad ? g.y_ld : g.x_ld;
     if (Kc % 8 != 0 || in_ld % (bf ? 8 : 4) != 0) return false;   // 16-byte staging pieces
     if (Nc < 8) return false;  // tiny outputs (e.g. 16->2) stay on the direct kernel
-    static const int use_v1 = getenv("MRI3D_FWD_V1") ? atoi(getenv("MRI3D_FWD_V1")) : 0;  // tuning aid (A/B)
-    p.v2 = (use_v1 && !bf) ? 0 : 1;
-    p.CK = bf ? 16 : ((Kc % 16 == 0 && !p.v2) ? 16 : 8);
+    p.CK = bf ? 16 : 8;
     p.NTT = cdiv(Nc, 16);
-    // NT (16-channel N-tiles per wave) is capped by registers: v1 holds 8*NT accumulators + 2-deep A / 3-deep B rings
-    // (NT <= 3); v2 adds the staging ring (NT <= 2).  Wider outputs are split over gy passes of the same tile.
-    if (p.NTT % 3 == 0 && !p.v2) p.NT = 3;
-    else if (p.NTT % 2 == 0) p.NT = 2;
-    else p.NT = 1;
+    // NT (16-channel N-tiles per wave) is capped by registers: 8*NT accumulators + 2-deep A / 3-deep B rings + the staging
+    // ring (NT <= 2).  Wider outputs are split over gy passes of the same tile.
+    p.NT = (p.NTT % 2 == 0) ? 2 : 1;
     p.gy = p.NTT / p.NT;
     p.nchunks = cdiv(Kc, p.CK);
     p.tilesD = cdiv(g.di, TD);
@@ -564,38 +435,22 @@ static bool mfma_fwd_plan(const Mri3dConvGeom& g, bool dgrad, MfmaFwdPlan& p) {
     int64_t nt = (int64_t)g.n * p.tilesD * p.tilesH * p.tilesW;
     if (nt > 0x7fffffff) return false;
     p.ntiles = (int)nt;
-    p.wp_floats = (size_t)p.nchunks * (bf ? 14 : tap_groups(p.CK)) * p.NTT * 256;   // 1 KiB per (chunk, tap group, N-tile)
-    p.smem = p.v2 ? (size_t)2 * kStg * 256 * 16 : (size_t)HVOX * p.CK * sizeof(float);
-    if (p.v2) {
-        int64_t st = (int64_t)p.ntiles * p.gy;  // (spatial tile, n-tile block) work units
-        if (st > 0x7fffffff) return false;
-        p.grid = (int)std::min<int64_t>(st, 512);  // 2 resident workgroups per CU x 256 CUs
-    }
+    p.wp_floats = (size_t)p.nchunks * 14 * p.NTT * 256;   // 1 KiB per (chunk, tap group, N-tile)
+    p.smem = (size_t)2 * kStg * 256 * 16;
+    int64_t st = (int64_t)p.ntiles * p.gy;  // (spatial tile, n-tile block) work units
+    if (st > 0x7fffffff) return false;
+    p.grid = (int)std::min<int64_t>(st, 512);  // 2 resident workgroups per CU x 256 CUs
     return true;
-}
-
-template <int NT, int CK>
-static void launch_mfma_fwd(const MfmaFwdPlan& p, const float* in, const float* wp, const float* bias, float* out, int N,
-                            int D, int H, int W, int Kc, int in_ld, int Nc, int out_ld, hipStream_t s) {
-    auto kern = conv_mfma_fwd_kernel<NT, CK>;
-    if (p.smem > 64 * 1024)
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  (int)p.smem);
-    static const int ablate = getenv("MRI3D_ABLATE") ? atoi(getenv("MRI3D_ABLATE")) : 0;  // tuning aid: 1 = skip staging, 2 = skip MFMA loop, 4 = skip stores
-    hipLaunchKernelGGL(kern, dim3(p.ntiles, p.gy), dim3(256), p.smem, s, in, wp, bias, out, N, D, H, W, Kc, in_ld, Nc,
-                       out_ld, p.NTT, p.tilesD, p.tilesH, p.tilesW, p.ntiles, ablate);
 }
 
 static int run_mfma_fwd(const Mri3dConvGeom& g, bool dgrad, const void* in_v, const float* w, const float* bias,
                         void* out_v, void* ws, size_t ws_bytes, hipStream_t s) {
-    const float* in = static_cast<const float*>(in_v);   // fp32 views for the fp32-only v1 kernel below
-    float* out = static_cast<float*>(out_v);
     MfmaFwdPlan p;
     MRI3D_REQUIRE(mfma_fwd_plan(g, dgrad, p), MRI3D_ENOTSUP, "conv3d(mfma): unsupported geometry");
     MRI3D_REQUIRE(ws && ws_bytes >= p.wp_floats * sizeof(float), MRI3D_EWORKSPACE, "conv3d(mfma): workspace %zu < %zu",
                   ws_bytes, p.wp_floats * sizeof(float));
-    MRI3D_REQUIRE((reinterpret_cast<uintptr_t>(in) & 15) == 0 && (reinterpret_cast<uintptr_t>(ws) & 15) == 0,
-                  MRI3D_EINVAL, "conv3d(mfma): input/workspace must be 16-byte aligned");
+    MRI3D_REQUIRE(((reinterpret_cast<uintptr_t>(in_v) | reinterpret_cast<uintptr_t>(out_v) | reinterpret_cast<uintptr_t>(ws)) & 15) == 0,
+                  MRI3D_EINVAL, "conv3d(mfma): input/output/workspace must be 16-byte aligned");
     float* wp = static_cast<float*>(ws);
     const int Kc = dgrad ? g.co : g.ci, Nc = dgrad ? g.ci : g.co;
     const int in_ld = dgrad ? g.y_ld : g.x_ld, out_ld = dgrad ? g.x_ld : g.y_ld;
@@ -605,35 +460,23 @@ static int run_mfma_fwd(const Mri3dConvGeom& g, bool dgrad, const void* in_v, co
                            reinterpret_cast<bf16_t*>(wp), g.co, g.ci, dgrad ? 1 : 0, p.NTT, p.nchunks);
     else
         hipLaunchKernelGGL(pack_w_mfma_kernel, dim3(std::min(cdiv(total, 256), 2048)), dim3(256), 0, s, w, wp, g.co, g.ci,
-                           dgrad ? 1 : 0, p.CK, p.NTT, p.nchunks);
-    if (p.v2) {
-        const int st = p.ntiles * p.gy;
-        const size_t smem = p.smem;
+                           dgrad ? 1 : 0, 8, p.NTT, p.nchunks);
+    const int st = p.ntiles * p.gy;
+    const size_t smem = p.smem;
 #define MRI3D_FWD2_CASE(NTv)                                                                                          \
     if (p.NT == NTv) {                                                                                                \
         auto kern = conv_mfma_fwd2_kernel<T, NTv>;                                                                    \
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,   \
-                                  (int)smem);                                                                         \
+        static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),                       \
+                                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);    \
+        (void)attr;   /* once per kernel, not per launch */                                                          \
         hipLaunchKernelGGL(kern, dim3(p.grid), dim3(256), smem, s, (const T*)in_v, wp, bias, (T*)out_v, g.n, g.di,    \
                            g.hi, g.wi, Kc, in_ld, Nc, out_ld, p.NTT, p.gy, p.tilesD, p.tilesH, p.tilesW, st);        \
     }
-        MRI3D_DISPATCH_DTYPE(g.dtype, T, {
-            MRI3D_FWD2_CASE(1)
-            MRI3D_FWD2_CASE(2)
-        });
+    MRI3D_DISPATCH_DTYPE(g.dtype, T, {
+        MRI3D_FWD2_CASE(1)
+        MRI3D_FWD2_CASE(2)
+    });
 #undef MRI3D_FWD2_CASE
-        return check_launch(dgrad ? "conv3d_dgrad(mfma2)" : "conv3d_fwd(mfma2)");
-    }
-#define MRI3D_FWD_CASE(NTv, CKv)                                                                                      \
-    if (p.NT == NTv && p.CK == CKv)                                                                                   \
-        launch_mfma_fwd<NTv, CKv>(p, in, wp, bias, out, g.n, g.di, g.hi, g.wi, Kc, in_ld, Nc, out_ld, s);
-    MRI3D_FWD_CASE(1, 16)
-    MRI3D_FWD_CASE(2, 16)
-    MRI3D_FWD_CASE(3, 16)
-    MRI3D_FWD_CASE(1, 8)
-    MRI3D_FWD_CASE(2, 8)
-    MRI3D_FWD_CASE(3, 8)
-#undef MRI3D_FWD_CASE
     return check_launch(dgrad ? "conv3d_dgrad(mfma)" : "conv3d_fwd(mfma)");
 }
 
@@ -677,8 +520,7 @@ __device__ __forceinline__ int wg_tap_offset(int tap) {  // halo-voxel offset of
 template <typename T, int CK, bool BIAS>
 __global__ void __launch_bounds__(256, 2)
 conv_mfma_wgrad_kernel(const T* __restrict__ x, const T* __restrict__ dy, float* __restrict__ part, int N, int D,
-                       int H, int W, int Ci, int x_ld, int Co, int y_ld, int tilesD, int tilesH, int tilesW, int ntiles,
-                       int ablate) {
+                       int H, int W, int Ci, int x_ld, int Co, int y_ld, int tilesD, int tilesH, int tilesW, int ntiles) {
     constexpr int TG = wg_tap_groups(CK);
     constexpr int TGA = TG + (BIAS ? 1 : 0);
     constexpr int CP = CK;           // X tile voxel pitch (floats)
@@ -721,7 +563,6 @@ conv_mfma_wgrad_kernel(const T* __restrict__ x, const T* __restrict__ dy, float*
         const T* dn = dy + (int64_t)n * D * H * W * y_ld + cob * 16;
 
         __syncthreads();
-        if (!(ablate & 1))
         for (int idx = tid; idx < WHVOX * XQ; idx += 256) {
             const int q = idx % XQ, v = idx / XQ;
             const int wx = v % WHW;
@@ -737,7 +578,6 @@ conv_mfma_wgrad_kernel(const T* __restrict__ x, const T* __restrict__ dy, float*
                 xs[v * CP + q] = ok ? ldf(src) : 0.f;
             }
         }
-        if (!(ablate & 1))
         for (int idx = tid; idx < WVOX * 4; idx += 256) {
             const int q = idx & 3, v = idx >> 2;
             const int wx = v % WTW;
@@ -762,7 +602,6 @@ conv_mfma_wgrad_kernel(const T* __restrict__ x, const T* __restrict__ dy, float*
         }
         __syncthreads();
 
-        if (ablate & 2) continue;
 #pragma unroll 1
         for (int hr = 0; hr < 4; ++hr) {
             const int hy = hsel * 4 + hr;
@@ -1572,24 +1411,20 @@ static bool mfma_wgrad_plan(const Mri3dConvGeom& g, MfmaWgradPlan& p) {
     if (!(g.kd == 3 && g.kh == 3 && g.kw == 3 && g.sd == 1 && g.sh == 1 && g.sw == 1 && g.pd == 1 && g.ph == 1 &&
           g.pw == 1 && g.dd == 1 && g.dh == 1 && g.dw == 1))
         return false;
-    static const int use_v1 = getenv("MRI3D_WGRAD_V1") ? atoi(getenv("MRI3D_WGRAD_V1")) : 0;  // tuning aid (A/B)
-    // kernel version: 0 = v1 (any CK), 1 = v3 (CK = 8, register prefetch), 2 = v4 (CK = 16, small double-buffered tile)
-    // 3 = bf16 MFMA (bf16 tensors, Cin % 8 == 0: a 16-channel ci-tile whose upper half may be empty)
-    p.v2 = (!use_v1 && g.ci % 8 == 0 && g.co % 4 == 0 && g.y_ld % 4 == 0) ? (g.ci % 16 == 0 ? 2 : 1) : 0;
-    static const int no_bf = getenv("MRI3D_WGRAD_BF16_OFF") ? atoi(getenv("MRI3D_WGRAD_BF16_OFF")) : 0;   // tuning aid (A/B)
-    if (g.dtype == MRI3D_BF16 && !no_bf && g.ci % 8 == 0 && g.co % 8 == 0 && g.x_ld % 8 == 0 && g.y_ld % 8 == 0) p.v2 = 3;
-    // 4 = v6 (fp32 transposed-tile kernel): 110 / 104 / 102 TFLOP/s on 48->16 / 96->32 / 16->16 against v4's 103 / 90 / 99
-    static const int force_v6 = getenv("MRI3D_WGRAD_V6") ? atoi(getenv("MRI3D_WGRAD_V6")) : -1;   // tuning aid (A/B): 0 / 1
-    if (p.v2 == 2 && g.dtype == MRI3D_F32 && (force_v6 < 0 || force_v6 != 0)) p.v2 = 4;
+    // kernel: 0 = first-layer kernel (Cin = 1: 16 taps per M-tile), 1 = v3 (Cin % 8 == 0, register prefetch),
+    // 2 = v4 (Cin % 16 == 0, small double-buffered tile: only for bf16 tensors the bf16 MFMA kernel cannot take),
+    // 3 = bf16 MFMA (bf16 tensors, Cin % 8 == 0: a 16-channel ci-tile whose upper half may be empty),
+    // 4 = v6 (fp32, Cin % 16 == 0, transposed tile: 110 / 104 / 102 TFLOP/s on 48->16 / 96->32 / 16->16 against v4's 103 / 90 / 99)
+    p.v2 = (g.ci % 8 == 0 && g.co % 4 == 0 && g.y_ld % 4 == 0) ? (g.ci % 16 == 0 ? 2 : 1) : 0;
+    if (g.dtype == MRI3D_BF16 && g.ci % 8 == 0 && g.co % 8 == 0 && g.x_ld % 8 == 0 && g.y_ld % 8 == 0) p.v2 = 3;
+    if (p.v2 == 2 && g.dtype == MRI3D_F32) p.v2 = 4;
     if (p.v2 == 3) p.CK = 16;
-    else if (g.ci % 16 == 0) p.CK = 16;
-    else if (g.ci % 8 == 0) p.CK = 8;
+    else if (p.v2 != 0 && g.ci % 16 == 0) p.CK = 16;
+    else if (p.v2 != 0) p.CK = 8;
     else if (g.ci == 1) {
-        // Conv3d(1, 8|16, 3): the direct first-layer kernel of conv_generic.hip (conv_cin1_wgrad_kernel) takes these
-        static const int cin1_mfma = getenv("MRI3D_CIN1_MFMA") ? atoi(getenv("MRI3D_CIN1_MFMA")) : 0;   // tuning aid (A/B)
-        // (Co = 8: 0.25 vs 0.47 ms on 2 x 160x192x160; Co = 16 stays here: 0.22 vs 0.24 ms on 16 x 64^3)
-        if (!cin1_mfma && g.co == 8 && g.y_ld % 4 == 0) return false;
-        if (!cin1_mfma && g.co == 1) return false;   // the 1 -> 1 stencil (conv_c1c1_wgrad_kernel)
+        // Conv3d(1, 8, 3) and the 1 -> 1 stencil have direct kernels in conv_generic.hip (conv_cin1_wgrad_kernel: 0.25 vs
+        // 0.47 ms on 2 x 160x192x160; conv_c1c1_wgrad_kernel); Co = 16 stays here (0.22 vs 0.24 ms on 16 x 64^3)
+        if ((g.co == 8 && g.y_ld % 4 == 0) || g.co == 1) return false;
         p.CK = 1;
     } else return false;
     if (p.CK >= 4 && g.x_ld % 4 != 0) return false;
@@ -1642,23 +1477,24 @@ size_t conv_mfma_workspace_bytes(const Mri3dConvGeom& g, int pass) {
     return 0;
 }
 
-template <typename T, int CK>
-static void launch_mfma_wgrad(const MfmaWgradPlan& p, const Mri3dConvGeom& g, const T* x, const T* dy,
-                              float* part, bool bias, hipStream_t s) {
+// set a kernel's dynamic-LDS limit once (not per launch)
+#define MRI3D_SET_SMEM_ONCE(kern, bytes)                                                                              \
+    do {                                                                                                              \
+        static const hipError_t attr_ = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),                      \
+                                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)(bytes)); \
+        (void)attr_;                                                                                                  \
+    } while (0)
+
+template <typename T>
+static void launch_mfma_wgrad_cin1(const MfmaWgradPlan& p, const Mri3dConvGeom& g, const T* x, const T* dy,
+                                   float* part, bool bias, hipStream_t s) {
     dim3 grid(p.P, p.CIT, p.COB);
-    static const int ablate = getenv("MRI3D_ABLATE_W") ? atoi(getenv("MRI3D_ABLATE_W")) : 0;  // tuning aid
     if (bias) {
-        auto kern = conv_mfma_wgrad_kernel<T, CK, true>;
-        if (p.smem > 64 * 1024)
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.smem);
-        hipLaunchKernelGGL(kern, grid, dim3(256), p.smem, s, x, dy, part, g.n, g.di, g.hi, g.wi, g.ci, g.x_ld, g.co,
-                           g.y_ld, p.tilesD, p.tilesH, p.tilesW, p.ntiles, ablate);
+        hipLaunchKernelGGL((conv_mfma_wgrad_kernel<T, 1, true>), grid, dim3(256), p.smem, s, x, dy, part, g.n, g.di, g.hi, g.wi,
+                           g.ci, g.x_ld, g.co, g.y_ld, p.tilesD, p.tilesH, p.tilesW, p.ntiles);
     } else {
-        auto kern = conv_mfma_wgrad_kernel<T, CK, false>;
-        if (p.smem > 64 * 1024)
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.smem);
-        hipLaunchKernelGGL(kern, grid, dim3(256), p.smem, s, x, dy, part, g.n, g.di, g.hi, g.wi, g.ci, g.x_ld, g.co,
-                           g.y_ld, p.tilesD, p.tilesH, p.tilesW, p.ntiles, ablate);
+        hipLaunchKernelGGL((conv_mfma_wgrad_kernel<T, 1, false>), grid, dim3(256), p.smem, s, x, dy, part, g.n, g.di, g.hi, g.wi,
+                           g.ci, g.x_ld, g.co, g.y_ld, p.tilesD, p.tilesH, p.tilesW, p.ntiles);
     }
 }
 
@@ -1672,8 +1508,7 @@ static void run_mfma_wgrad(const MfmaWgradPlan& p, const Mri3dConvGeom& g, const
 #define MRI3D_WGB(Bv)                                                                                                 \
     {                                                                                                                 \
         auto kern = conv_mfma_wgrad_bf16_kernel<Bv>;                                                                  \
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,   \
-                                  (int)p.smem);                                                                       \
+        MRI3D_SET_SMEM_ONCE(kern, p.smem);                                                                            \
         hipLaunchKernelGGL(kern, grid, dim3(256), p.smem, s, x, dy, part, g.n, g.di, g.hi, g.wi, g.ci, g.x_ld, g.co,  \
                            g.y_ld, p.tilesD, p.tilesH, p.tilesW, p.ntiles);                                           \
     }
@@ -1686,8 +1521,7 @@ static void run_mfma_wgrad(const MfmaWgradPlan& p, const Mri3dConvGeom& g, const
 #define MRI3D_WG6(Bv)                                                                                                 \
     {                                                                                                                 \
         auto kern = conv_mfma_wgrad6_kernel<Bv>;                                                                      \
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,   \
-                                  (int)p.smem);                                                                       \
+        MRI3D_SET_SMEM_ONCE(kern, p.smem);                                                                            \
         hipLaunchKernelGGL(kern, grid, dim3(256), p.smem, s, x, dy, part, g.n, g.di, g.hi, g.wi, g.ci, g.x_ld, g.co,  \
                            g.y_ld, p.tilesD, p.tilesH, p.tilesW, p.ntiles);                                           \
     }
@@ -1695,33 +1529,33 @@ static void run_mfma_wgrad(const MfmaWgradPlan& p, const Mri3dConvGeom& g, const
 #undef MRI3D_WG6
         }
     } else if (p.v2 == 2) {
+      if constexpr (sizeof(T) == 2) {   // fp32 tensors with Cin % 16 == 0 always take v6
         dim3 grid(p.P, p.CIT, p.COB);
 #define MRI3D_WG4(Bv)                                                                                                 \
     {                                                                                                                 \
         auto kern = conv_mfma_wgrad4_kernel<T, Bv>;                                                                   \
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,   \
-                                  (int)p.smem);                                                                       \
+        MRI3D_SET_SMEM_ONCE(kern, p.smem);                                                                            \
         hipLaunchKernelGGL(kern, grid, dim3(256), p.smem, s, x, dy, part, g.n, g.di, g.hi, g.wi, g.ci, g.x_ld, g.co,  \
                            g.y_ld, p.tilesD, p.tilesH, p.tilesW, p.ntiles);                                           \
     }
         if (bias) MRI3D_WG4(true) else MRI3D_WG4(false)
 #undef MRI3D_WG4
+      }
     } else if (p.v2 == 1) {
         dim3 grid(p.P, p.CIT, p.COB);
 #define MRI3D_WG3(CKv, Bv)                                                                                            \
     {                                                                                                                 \
         auto kern = conv_mfma_wgrad3_kernel<T, CKv, Bv>;                                                              \
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,   \
-                                  (int)p.smem);                                                                       \
+        MRI3D_SET_SMEM_ONCE(kern, p.smem);                                                                            \
         hipLaunchKernelGGL(kern, grid, dim3(256), p.smem, s, x, dy, part, g.n, g.di, g.hi, g.wi, g.ci, g.x_ld, g.co,  \
                            g.y_ld, p.tilesD, p.tilesH, p.tilesW, p.ntiles);                                           \
     }
         if (bias) MRI3D_WG3(8, true)
         else MRI3D_WG3(8, false)
 #undef MRI3D_WG3
-    } else if (p.CK == 16) launch_mfma_wgrad<T, 16>(p, g, x, dy, part, bias, s);
-    else if (p.CK == 8) launch_mfma_wgrad<T, 8>(p, g, x, dy, part, bias, s);
-    else launch_mfma_wgrad<T, 1>(p, g, x, dy, part, bias, s);
+    } else {
+        launch_mfma_wgrad_cin1<T>(p, g, x, dy, part, bias, s);
+    }
 }
 
 int conv_mfma_wgrad(const Mri3dConvGeom& g, const void* x, const void* dy, float* dw, float* dbias, void* ws,

@@ -744,7 +744,7 @@ extern "C" int mri3d_upsample3d_fwd(const Mri3dUpGeom* g, const void* x, void* y
     if (rc) return rc;
     MRI3D_REQUIRE(x && y, MRI3D_EINVAL, "upsample3d_fwd: null pointer");
     hipStream_t s = static_cast<hipStream_t>(stream);
-    static const int no_fast_f = getenv("MRI3D_UP_GENERIC") ? atoi(getenv("MRI3D_UP_GENERIC")) : 0;   // tuning aid (A/B)
+    static const int no_fast_f = tuning_knob("MRI3D_UP_GENERIC", 0);   // tuning aid (A/B)
     if (!no_fast_f && up2x_fast_ok(*g) && aligned_vec4(g->dtype, x, y)) {
         const int tilesD = cdiv(g->di, FTD), tilesH = cdiv(g->hi, FTH), tilesW = cdiv(g->wi, FTWD);
         const int64_t nt = (int64_t)g->n * tilesD * tilesH * tilesW;
@@ -778,9 +778,9 @@ extern "C" int mri3d_upsample3d_bwd(const Mri3dUpGeom* g, const void* dy, void* 
     MRI3D_REQUIRE(workspace && ws_bytes >= mri3d_upsample3d_workspace_bytes(g), MRI3D_EWORKSPACE,
                   "upsample3d_bwd: workspace %zu < %zu", ws_bytes, mri3d_upsample3d_workspace_bytes(g));
     hipStream_t s = static_cast<hipStream_t>(stream);
-    static const int no_fast = getenv("MRI3D_UP_GENERIC") ? atoi(getenv("MRI3D_UP_GENERIC")) : 0;   // tuning aid (A/B)
+    static const int no_fast = tuning_knob("MRI3D_UP_GENERIC", 0);   // tuning aid (A/B)
     if (!no_fast && up2x_fast_ok(*g) && aligned_vec4(g->dtype, dx, dy)) {
-        static const int march = getenv("MRI3D_UP_MARCH") ? atoi(getenv("MRI3D_UP_MARCH")) : 1;   // tuning aid (A/B)
+        static const int march = tuning_knob("MRI3D_UP_MARCH", 1);   // tuning aid (A/B)
         if (march && g->c % 16 == 0) {
             const int segsD = cdiv(g->di, MD), tilesH = cdiv(g->hi, MTH), tilesW = cdiv(g->wi, MTW), cpasses = g->c / 16;
             const int64_t items = (int64_t)g->n * segsD * cpasses * tilesH * tilesW;

@@ -27,6 +27,23 @@ def _cases(n, seed):
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
 @pytest.mark.parametrize("case", _cases(14, 2024), ids=lambda c: "n%d_%d-%d_%dx%dx%d_p%d_%d" % c[:8])
 def test_conv3x3x3_random_geometry(case, dtype):
+    _run_conv_case(case, dtype)
+
+
+# channel slices whose base address is NOT 16-byte aligned (pad_in = 2 fp32 elements / 2 or 4 bf16 elements, odd pitches):
+# legal inputs that the MFMA kernels (16-byte pieces) cannot take — the dispatcher must fall back to the generic kernels
+# instead of failing with EINVAL
+MISALIGNED = [(1, 16, 16, 5, 9, 20, 2, 0, 11), (2, 8, 16, 4, 8, 16, 2, 2, 12), (1, 48, 16, 3, 8, 17, 4, 4, 13),
+              (1, 16, 32, 6, 10, 18, 6, 0, 14), (1, 32, 32, 2, 3, 5, 1, 3, 15)]
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
+@pytest.mark.parametrize("case", MISALIGNED, ids=lambda c: "n%d_%d-%d_%dx%dx%d_p%d_%d" % c[:8])
+def test_conv3x3x3_misaligned_channel_slices_fall_back_to_generic_kernels(case, dtype):
+    _run_conv_case(case, dtype)
+
+
+def _run_conv_case(case, dtype):
     nb, ci, co, d, h, w, pad_in, pad_out, seed = case
     g = torch.Generator().manual_seed(seed)
     x = torch.randn(nb, ci, d, h, w, generator=g)
