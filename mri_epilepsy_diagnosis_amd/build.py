@@ -65,5 +65,49 @@ def build(force=False, jobs=4, verbose=True):
     return LIB
 
 
+def build_host_sanitizer(verbose=True):
+    """Host-only AddressSanitizer + UBSan build of the library's host code (argument validation, plan / dispatch selection,
+    workspace sizing) linked with tests/native/host_sanitizer_driver.cpp into ONE executable; the sanitizers instrument the host
+    side only (-fno-gpu-sanitize) and the driver only takes paths that return before a kernel launch.  GPU ASan is unavailable on this
+    pool.  Returns the executable's path (cached by a digest of every input)."""
+    root = os.path.join(HERE, "..")
+    driver = os.path.join(root, "tests", "native", "host_sanitizer_driver.cpp")
+    out_dir = os.path.join(root, "tests", "native", "build")
+    os.makedirs(out_dir, exist_ok=True)
+    exe = os.path.join(out_dir, "host_sanitizer_driver")
+    # the device side is compiled normally (-fno-gpu-sanitize: the fat binary must exist for the module constructor) and never runs
+    flags = ["--offload-arch=gfx950", "-fsanitize=address,undefined", "-fno-gpu-sanitize", "-fno-sanitize-recover=undefined", "-fno-omit-frame-pointer",
+             "-O1", "-g", "-std=c++17", "-w", "-I", os.path.join(root, "include")]
+    h = hashlib.sha256(" ".join(flags).encode())
+    inputs = [os.path.join(CSRC, s) for s in SOURCES] + [os.path.join(CSRC, "common.h"), os.path.join(root, "include", "mri3d.h"), driver]
+    for f in inputs:
+        with open(f, "rb") as fh:
+            h.update(fh.read())
+    stamp = exe + ".sha"
+    if os.path.exists(exe) and os.path.exists(stamp) and open(stamp).read() == h.hexdigest():
+        return exe
+
+    def one(src):
+        obj = os.path.join(out_dir, os.path.basename(src).rsplit(".", 1)[0] + ".host.o")
+        cmd = [HIPCC] + flags + (["-x", "hip"] if src.endswith(".hip") else []) + ["-c", src, "-o", obj]
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=900)
+        if r.returncode != 0:
+            raise RuntimeError("host sanitizer build failed for %s:\n%s" % (src, r.stderr[-3000:]))
+        return obj
+    with ThreadPoolExecutor(max_workers=4) as ex:
+        objs = list(ex.map(one, [os.path.join(CSRC, s) for s in SOURCES] + [driver]))
+    r = subprocess.run([HIPCC, "--offload-arch=gfx950", "-fsanitize=address,undefined", "-fno-gpu-sanitize", "-o", exe] + objs, capture_output=True, text=True, timeout=600)
+    if r.returncode != 0:
+        raise RuntimeError("host sanitizer link failed:\n%s" % r.stderr[-3000:])
+    with open(stamp, "w") as f:
+        f.write(h.hexdigest())
+    if verbose:
+        print("built", exe)
+    return exe
+
+
 if __name__ == "__main__":
-    build(force="--force" in sys.argv)
+    if "--host-sanitizer" in sys.argv:
+        print(build_host_sanitizer())
+    else:
+        build(force="--force" in sys.argv)

@@ -18,20 +18,24 @@ import torch.nn as tnn
 import torch.nn.functional as F
 
 from .. import nn as mnn
+from .. import parallel
 
 
 def run_one_epoch(model, loader, criterion, train, device, optimizer=None, scheduler=None, experiment=False):
+    """classification/routine.py:15-52.  On the device, forward + criterion (+ backward) of a batch shape are captured once
+    into a hipGraph and replayed (parallel.StepCache); the optimizer and the per-batch `scheduler.step(loss)` stay eager."""
     model.to(device)
     model.train(train)
+    cache = parallel.StepCache.of(model)
     losses, probs, targets = [], [], []
     for data, target, _ in loader:
         data = data.to(device, dtype=torch.float)
         target = target.long().to(device)
-        outputs = model(data)
-        loss = criterion(outputs, target)
-        if train and optimizer is not None:
+        step = train and optimizer is not None
+        if step:
             optimizer.zero_grad()
-            loss.backward()
+        outputs, loss = cache.run(data, target, criterion, backward=step)
+        if step:
             optimizer.step()
             if scheduler is not None:
                 scheduler.step(loss)

@@ -66,6 +66,11 @@ def _esz(t):
 _autocast_dtype = None
 
 
+def autocast_dtype():
+    """The storage dtype of the active `autocast` region, or None."""
+    return _autocast_dtype
+
+
 class autocast:
     def __init__(self, enabled=True, dtype=torch.bfloat16):
         if dtype is not torch.bfloat16:
@@ -222,13 +227,39 @@ def set_timer(t):
     _timer = t
 
 
-class _timed:
-    """with _timed(tag, work): <C-ABI call>  — `work` = dict(flops=..., bytes=...) algorithmic figures per call."""
+_roctx = None
 
-    def __init__(self, tag, work=None):
-        self.tag, self.work = tag, work
+
+def set_roctx(enabled=True):
+    """roctx ranges around every C-ABI call: `rocprofv3 --marker-trace` then shows one range per operator, named
+    like the bench's operator tags.  Off by default (a range costs two library calls per operator)."""
+    global _roctx
+    if not enabled:
+        _roctx = None
+        return
+    h = ctypes.CDLL("libroctx64.so")
+    h.roctxRangePushA.argtypes = [ctypes.c_char_p]
+    h.roctxRangePushA.restype = ctypes.c_int
+    h.roctxRangePop.restype = ctypes.c_int
+    _roctx = h
+
+
+class _timed:
+    """with _timed(tag_fn, work_fn): <C-ABI call>  — tag_fn() names the operator, work_fn() = dict(flops=..., bytes=...)
+    algorithmic figures per call; both are only evaluated when a timer or roctx is installed (no string formatting on the
+    normal path)."""
+
+    __slots__ = ("tag_fn", "work_fn", "e0", "tag")
+
+    def __init__(self, tag_fn, work_fn=None):
+        self.tag_fn, self.work_fn = tag_fn, work_fn
 
     def __enter__(self):
+        if _timer is None and _roctx is None:
+            return
+        self.tag = self.tag_fn()
+        if _roctx is not None:
+            _roctx.roctxRangePushA(self.tag.encode())
         if _timer is not None:
             self.e0 = torch.cuda.Event(enable_timing=True)
             self.e0.record()
@@ -237,7 +268,9 @@ class _timed:
         if _timer is not None:
             e1 = torch.cuda.Event(enable_timing=True)
             e1.record()
-            _timer.records.append((self.tag, self.work, self.e0, e1))
+            _timer.records.append((self.tag, self.work_fn() if self.work_fn is not None else None, self.e0, e1))
+        if _roctx is not None:
+            _roctx.roctxRangePop()
         return False
 
 
@@ -289,7 +322,7 @@ def _conv_fwd(g, x, w, b):
     y = _new((g.n, g.co, g.dout, g.ho, g.wo), x)
     nb = L.mri3d_conv3d_workspace_bytes(ctypes.byref(g), PASS_FWD)
     ws = _workspace(nb, x.device)
-    with _timed(_conv_tag("fwd", g), _conv_work(g, "fwd")):
+    with _timed(lambda: _conv_tag("fwd", g), lambda: _conv_work(g, "fwd")):
         check(L.mri3d_conv3d_fwd(ctypes.byref(g), _ptr(x), _ptr(w), _ptr(b), _ptr(y), _ptr(ws), ws.numel(), _stream()),
               "conv3d_fwd")
     return y
@@ -300,7 +333,7 @@ def _conv_dgrad(g, dy, w, b, like):
     dx = _new((g.n, g.ci, g.di, g.hi, g.wi), like)
     nb = L.mri3d_conv3d_workspace_bytes(ctypes.byref(g), PASS_DGRAD)
     ws = _workspace(nb, dy.device)
-    with _timed(_conv_tag("dgrad", g), _conv_work(g, "dgrad")):
+    with _timed(lambda: _conv_tag("dgrad", g), lambda: _conv_work(g, "dgrad")):
         check(L.mri3d_conv3d_dgrad(ctypes.byref(g), _ptr(dy), _ptr(w), _ptr(b), _ptr(dx), _ptr(ws), ws.numel(),
                                    _stream()), "conv3d_dgrad")
     return dx
@@ -352,7 +385,7 @@ def _conv_wgrad(g, x, dy, w_like, want_bias, dw_out=None, db_out=None):
     db = (db_out if db_out is not None else torch.empty(g.co, dtype=w_like.dtype, device=w_like.device)) if want_bias else None
     nb = L.mri3d_conv3d_workspace_bytes(ctypes.byref(g), PASS_WGRAD)
     ws = _workspace(nb, x.device)
-    with _timed(_conv_tag("wgrad", g), _conv_work(g, "wgrad")):
+    with _timed(lambda: _conv_tag("wgrad", g), lambda: _conv_work(g, "wgrad")):
         check(L.mri3d_conv3d_wgrad(ctypes.byref(g), _ptr(x), _ptr(dy), _ptr(dw), _ptr(db), _ptr(ws), ws.numel(),
                                    _stream()), "conv3d_wgrad")
     return dw, db
@@ -523,7 +556,7 @@ class _NormActFn(torch.autograd.Function):
             invstd = torch.empty(groups * c, dtype=torch.float32, device=x.device)
             ws = _workspace(L.mri3d_norm_workspace_bytes(ctypes.byref(g)), x.device)
             upd = stats_mode == "batch" and running_mean is not None
-            with _timed("norm_stats c%d vox%d n%d" % (c, g.vox, n), {"flops": 0.0, "bytes": _esz(x) * x.numel()}):
+            with _timed(lambda: "norm_stats c%d vox%d n%d" % (c, g.vox, n), lambda: {"flops": 0.0, "bytes": _esz(x) * x.numel()}):
                 check(L.mri3d_norm_stats(ctypes.byref(g), _ptr(x), _ptr(mean), _ptr(invstd),
                                          _ptr(running_mean) if upd else None, _ptr(running_var) if upd else None,
                                          float(momentum), _ptr(ws), ws.numel(), _stream()), "norm_stats")
@@ -535,7 +568,7 @@ class _NormActFn(torch.autograd.Function):
             mean_l = torch.empty(c, dtype=torch.float32, device=x.device)
             invstd_l = torch.empty(c, dtype=torch.float32, device=x.device)
             ws = _workspace(L.mri3d_norm_workspace_bytes(ctypes.byref(g)), x.device)
-            with _timed("norm_stats c%d vox%d n%d" % (c, g.vox, n), {"flops": 0.0, "bytes": _esz(x) * x.numel()}):
+            with _timed(lambda: "norm_stats c%d vox%d n%d" % (c, g.vox, n), lambda: {"flops": 0.0, "bytes": _esz(x) * x.numel()}):
                 check(L.mri3d_norm_stats(ctypes.byref(g), _ptr(x), _ptr(mean_l), _ptr(invstd_l), None, None, float(momentum),
                                          _ptr(ws), ws.numel(), _stream()), "norm_stats")
             cnt_l = float(n * g.vox)
@@ -558,7 +591,7 @@ class _NormActFn(torch.autograd.Function):
         elif stats_mode == "running":
             mean = running_mean.detach().to(torch.float32).contiguous()
             invstd = torch.rsqrt(running_var.detach().to(torch.float32) + eps).contiguous()
-        with _timed("norm_act_fwd c%d vox%d n%d" % (c, g.vox, n), {"flops": 0.0, "bytes": 2 * _esz(x) * x.numel()}):
+        with _timed(lambda: "norm_act_fwd c%d vox%d n%d" % (c, g.vox, n), lambda: {"flops": 0.0, "bytes": 2 * _esz(x) * x.numel()}):
             check(L.mri3d_norm_act_fwd(ctypes.byref(g), _ptr(x), _ptr(mean), _ptr(invstd), _ptr(gamma), _ptr(beta),
                                        _ptr(alpha) if act_code == ACT_PRELU else None, _ptr(y), _stream()),
                   "norm_act_fwd")
@@ -603,7 +636,7 @@ class _NormActFn(torch.autograd.Function):
         else:
             dbeta_k, dgamma_k = dbeta, dgamma
         ws = _workspace(L.mri3d_norm_workspace_bytes(ctypes.byref(g)), x.device)
-        with _timed("norm_act_bwd c%d vox%d n%d" % (g.c, g.vox, g.n), {"flops": 0.0, "bytes": 5 * _esz(x) * x.numel()}):
+        with _timed(lambda: "norm_act_bwd c%d vox%d n%d" % (g.c, g.vox, g.n), lambda: {"flops": 0.0, "bytes": 5 * _esz(x) * x.numel()}):
             check(L.mri3d_norm_act_bwd(ctypes.byref(g), 1 if ctx.training_stats else 0, _ptr(x), _ptr(dy), _ptr(mean),
                                        _ptr(invstd), _ptr(gamma), _ptr(beta), _ptr(alpha) if prelu else None, _ptr(dx),
                                        _ptr(dgamma_k), _ptr(dbeta_k), _ptr(dalpha), _ptr(ws), ws.numel(), _stream()),
@@ -704,7 +737,7 @@ class _MaxPool3dFn(torch.autograd.Function):
         g = PoolGeom(n, d, h, w, do, ho, wo, c, *kernel, *stride, *padding, x_ld, c, _dt(x))
         y = _new((n, c, do, ho, wo), x)
         idx = torch.empty(n * do * ho * wo * c, dtype=torch.uint8, device=x.device)
-        with _timed("maxpool_fwd c%d" % c, {"flops": 0.0, "bytes": _esz(x) * x.numel() + (_esz(x) + 1) * y.numel()}):
+        with _timed(lambda: "maxpool_fwd c%d" % c, lambda: {"flops": 0.0, "bytes": _esz(x) * x.numel() + (_esz(x) + 1) * y.numel()}):
             check(L.mri3d_maxpool3d_fwd(ctypes.byref(g), _ptr(x), _ptr(y), _ptr(idx), _stream()), "maxpool3d_fwd")
         ctx.save_for_backward(idx)
         ctx.geom = g
@@ -720,7 +753,7 @@ class _MaxPool3dFn(torch.autograd.Function):
         g0 = ctx.geom
         g = PoolGeom(g0.n, g0.di, g0.hi, g0.wi, g0.dout, g0.ho, g0.wo, g0.c, g0.kd, g0.kh, g0.kw, g0.sd, g0.sh, g0.sw,
                      g0.pd, g0.ph, g0.pw, g0.c, dy_ld, _dt(dy))
-        with _timed("maxpool_bwd c%d" % g.c, {"flops": 0.0, "bytes": _esz(dy) * dx.numel() + (_esz(dy) + 1) * dy.numel()}):
+        with _timed(lambda: "maxpool_bwd c%d" % g.c, lambda: {"flops": 0.0, "bytes": _esz(dy) * dx.numel() + (_esz(dy) + 1) * dy.numel()}):
             check(L.mri3d_maxpool3d_bwd(ctypes.byref(g), _ptr(dy), _ptr(idx), _ptr(dx), _stream()), "maxpool3d_bwd")
         return dx, None, None, None
 
@@ -752,8 +785,7 @@ class _MaxPoolSkipFn(torch.autograd.Function):
         g0 = ctx.geom
         g = PoolGeom(g0.n, g0.di, g0.hi, g0.wi, g0.dout, g0.ho, g0.wo, g0.c, g0.kd, g0.kh, g0.kw, g0.sd, g0.sh, g0.sw,
                      g0.pd, g0.ph, g0.pw, g0.c, dy_ld, _dt(dy))
-        with _timed("maxpool_bwd+skip c%d" % g.c,
-                    {"flops": 0.0, "bytes": _esz(dy) * 2 * dx.numel() + (_esz(dy) + 1) * dy.numel()}):
+        with _timed(lambda: "maxpool_bwd+skip c%d" % g.c, lambda: {"flops": 0.0, "bytes": _esz(dy) * 2 * dx.numel() + (_esz(dy) + 1) * dy.numel()}):
             check(L.mri3d_maxpool3d_bwd_add(ctypes.byref(g), _ptr(dy), _ptr(idx), _ptr(dskip), ds_ld, _ptr(dx), _stream()),
                   "maxpool3d_bwd_add")
         return dx, None, None, None
@@ -795,7 +827,7 @@ class _Upsample3dFn(torch.autograd.Function):
             y = _slice_view(buf, y_off, c)
         g = UpGeom(n, d, h, w, do, ho, wo, c, x_ld, y_ld, mode, 1 if align_corners else 0, ratios[0], ratios[1], ratios[2],
                    _dt(x))
-        with _timed("upsample_fwd c%d" % c, {"flops": 0.0, "bytes": _esz(x) * (x.numel() + y.numel())}):
+        with _timed(lambda: "upsample_fwd c%d" % c, lambda: {"flops": 0.0, "bytes": _esz(x) * (x.numel() + y.numel())}):
             check(L.mri3d_upsample3d_fwd(ctypes.byref(g), _ptr(x), _ptr(y), _stream()), "upsample3d_fwd")
         ctx.geom = g
         ctx.xshape = tuple(x.shape)
@@ -810,7 +842,7 @@ class _Upsample3dFn(torch.autograd.Function):
         g = UpGeom(g0.n, g0.di, g0.hi, g0.wi, g0.dout, g0.ho, g0.wo, g0.c, g0.c, dy_ld, g0.mode, g0.align_corners, g0.rd,
                    g0.rh, g0.rw, _dt(dy))
         ws = _workspace(L.mri3d_upsample3d_workspace_bytes(ctypes.byref(g)), dy.device)
-        with _timed("upsample_bwd c%d" % g.c, {"flops": 0.0, "bytes": _esz(dy) * (dx.numel() + dy.numel())}):
+        with _timed(lambda: "upsample_bwd c%d" % g.c, lambda: {"flops": 0.0, "bytes": _esz(dy) * (dx.numel() + dy.numel())}):
             check(L.mri3d_upsample3d_bwd(ctypes.byref(g), _ptr(dy), _ptr(dx), _ptr(ws), ws.numel(), _stream()),
                   "upsample3d_bwd")
         return dx, None, None, None, None, None

@@ -190,3 +190,146 @@ class CapturedStep:
             return self._eager()
         self.graph.replay()
         return self.loss
+
+
+def _ensure_attached(flat):
+    """Make every parameter's .grad the view into flat.grad again (a caller's optimizer.zero_grad(set_to_none=True) or an eager
+    step in between drops / replaces them) WITHOUT zeroing: a graph replay has just written the gradients there."""
+    off = 0
+    for p in flat.params:
+        n = p.numel()
+        if p.grad is None or p.grad.data_ptr() != flat.grad.data_ptr() + off * flat.grad.element_size():
+            p.grad = flat.grad[off:off + n].view(p.shape)
+        sink = getattr(p, "_mri3d_grad_sink", None)
+        if sink is None or sink.view.data_ptr() != p.grad.data_ptr():
+            p._mri3d_grad_sink = ops.GradSink(p.grad)
+        off += n
+
+
+class StepCache:
+    """What makes the drop-in loops fast by default (segmentation/routine.py::run_epoch, classification/routine.py::
+    run_one_epoch): per model, a cache of hipGraph-captured `zero_grad -> forward -> loss [-> backward]` sequences keyed by the
+    input signature.  The first batch of a new shape is captured (its warm-up runs are undone: module buffers and the RNG state
+    are restored, so BatchNorm running statistics / num_batches_tracked advance exactly once per batch, as in the reference
+    loop); later batches copy into the static inputs and replay.  Anything that cannot be captured (CPU modules or tensors — the
+    oracle-driven CPU tests —, a capture error) runs eagerly: same kernels, same results, only more launch overhead.
+
+        cache = StepCache.of(model)
+        out, loss = cache.run(inputs, targets, loss_fn, backward=True)     # loss_fn(outputs, targets) -> scalar tensor
+        optimizer.step()                                                    # gradients are in p.grad (views of one flat buffer)
+
+    `out` and `loss` are static tensors, valid until the next run() with the same signature."""
+
+    MAX_ENTRIES = 8   # captured graphs kept per model (least recently used one is dropped: each holds its activations)
+
+    def __init__(self, model):
+        self.model = model
+        self.flat = None
+        self.entries = {}
+        self.disabled = False
+        self.replays = self.captures = self.eager_runs = 0
+
+    @staticmethod
+    def of(model):
+        c = getattr(model, "_mri3d_step_cache", None)
+        if c is None:
+            c = StepCache(model)
+            object.__setattr__(model, "_mri3d_step_cache", c)   # plain attribute: not a sub-module, not in the state_dict
+        return c
+
+    def _capturable(self, inputs, targets):
+        if self.disabled or not torch.cuda.is_available() or not inputs.is_cuda or (targets is not None and not targets.is_cuda):
+            return False
+        ps = list(self.model.parameters())
+        return bool(ps) and all(p.is_cuda for p in ps)
+
+    def _signature(self, inputs, targets, loss_fn, backward):
+        m = self.model
+        modes = tuple(mod.training for mod in m.modules())
+        grads = tuple(p.requires_grad for p in m.parameters())
+        if isinstance(loss_fn, torch.nn.Module) and not any(True for _ in loss_fn.parameters()) and not any(True for _ in loss_fn.buffers()):
+            loss_key = (type(loss_fn), repr(loss_fn))     # e.g. a fresh nn.CrossEntropyLoss() per train() call is the same loss
+        else:
+            loss_key = loss_fn
+        return (tuple(inputs.shape), inputs.dtype, None if targets is None else (tuple(targets.shape), targets.dtype),
+                loss_key, bool(backward), torch.is_grad_enabled(), ops.autocast_dtype(), hash(modes), hash(grads),
+                inputs.device.index)
+
+    def _eager(self, inputs, targets, loss_fn, backward):
+        self.eager_runs += 1
+        out = self.model(inputs)
+        loss = loss_fn(out, targets) if loss_fn is not None else None
+        if backward:
+            loss.backward()
+        return out, loss
+
+    def run(self, inputs, targets=None, loss_fn=None, backward=False):
+        if not self._capturable(inputs, targets):
+            return self._eager(inputs, targets, loss_fn, backward)
+        key = self._signature(inputs, targets, loss_fn, backward)
+        e = self.entries.get(key)
+        if e is None:
+            try:
+                e = self._capture(inputs, targets, loss_fn, backward)
+            except Exception as exc:  # noqa: BLE001 — capture support is a property of the runtime / the model, not of the data
+                import warnings
+                warnings.warn("mri3d: hipGraph capture of the training step failed (%s: %s); running eagerly from now on"
+                              % (type(exc).__name__, exc))
+                self.disabled = True
+                torch.cuda.synchronize()
+                if backward:
+                    for p in self.model.parameters():
+                        p.grad = None
+                return self._eager(inputs, targets, loss_fn, backward)
+            if len(self.entries) >= self.MAX_ENTRIES:
+                del self.entries[next(iter(self.entries))]
+            self.entries[key] = e
+        else:
+            self.entries[key] = self.entries.pop(key)     # most recently used last
+        e["x"].copy_(inputs)
+        if targets is not None:
+            e["t"].copy_(targets)
+        e["graph"].replay()
+        self.replays += 1
+        if backward:
+            _ensure_attached(self.flat)
+        return e["out"], e["loss"]
+
+    def _capture(self, inputs, targets, loss_fn, backward):
+        m = self.model
+        if backward and self.flat is None:
+            self.flat = FlatParams(m)
+        x = inputs.clone()
+        t = targets.clone() if targets is not None else None
+        grad_mode = torch.is_grad_enabled()
+
+        def body():
+            if backward:
+                self.flat.zero_grad()
+            with torch.set_grad_enabled(grad_mode):
+                out = m(x)
+                loss = loss_fn(out, t) if loss_fn is not None else None
+                if backward:
+                    loss.backward()
+            return out, loss
+
+        # the warm-up runs (allocator pools, lazy workspaces) must leave no trace: buffers (BatchNorm running statistics,
+        # num_batches_tracked) and the generator state are put back before the graph's first replay handles this batch
+        bufs = [b.detach().clone() for b in m.buffers()]
+        rng = torch.cuda.get_rng_state(inputs.device)
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            for _ in range(2):
+                body()
+        torch.cuda.current_stream().wait_stream(s)
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            out, loss = body()
+        with torch.no_grad():
+            for b, saved in zip(m.buffers(), bufs):
+                b.copy_(saved)
+        torch.cuda.set_rng_state(rng, inputs.device)
+        self.captures += 1
+        return {"graph": g, "x": x, "t": t, "out": out, "loss": loss}

@@ -23,7 +23,7 @@ import warnings
 import numpy as np
 import torch
 
-from .. import ops
+from .. import ops, parallel
 from . import surface
 from ..unet import UNet
 
@@ -131,19 +131,23 @@ def forward(model, inputs):
 
 
 def run_epoch(epoch_idx, action, loader, model, optimizer, scheduler=False, experiment=False, loss_fn=None):
-    """One pass over `loader`.  `loss_fn(logits, targets)` defaults to the fused softmax+Dice HIP kernel."""
+    """One pass over `loader` (segmentation/routine.py:261-294: zero_grad -> forward -> softmax-Dice -> backward -> step ->
+    .item()).  `loss_fn(logits, targets)` defaults to the fused softmax+Dice HIP kernel.  On the device the sequence
+    zero_grad -> forward -> loss (-> backward) is captured once per batch shape into a hipGraph and replayed
+    (parallel.StepCache: same kernels, same results, one launch instead of ~300); CPU modules / tensors (the oracle-driven host
+    tests) and anything that cannot be captured run eagerly."""
     is_training = action == Action.TRAIN
     loss_fn = ops.softmax_dice_loss if loss_fn is None else loss_fn
     epoch_losses = []
     model.train(is_training)
+    cache = parallel.StepCache.of(model)
     for batch in loader:
         inputs, targets = prepare_batch(batch, device)
         optimizer.zero_grad()
-        with torch.set_grad_enabled(is_training):
-            logits = forward(model, inputs)
-            batch_loss = loss_fn(logits, targets)
+        with torch.set_grad_enabled(is_training), warnings.catch_warnings():
+            warnings.filterwarnings("ignore", category=UserWarning)
+            logits, batch_loss = cache.run(inputs, targets, loss_fn, backward=is_training)
             if is_training:
-                batch_loss.backward()
                 optimizer.step()
             epoch_losses.append(batch_loss.item())
             if experiment:

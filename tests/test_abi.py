@@ -72,3 +72,17 @@ def test_workspace_queries_are_host_only():
     g = _lib.ConvGeom(2, 160, 192, 160, 48, 160, 192, 160, 16, 3, 3, 3, 1, 1, 1, 1, 1, 1, 1, 1, 1, 48, 16, 0)
     for p in (0, 1, 2):
         assert L.mri3d_conv3d_workspace_bytes(ctypes.byref(g), p) > 0
+
+
+def test_host_code_is_clean_under_address_and_ub_sanitizers():
+    """the library's HOST side (argument validation, plan / dispatch selection, workspace sizing, error strings)
+    built with -fsanitize=address,undefined and driven without a GPU by tests/native/host_sanitizer_driver.cpp: > 100 000
+    workspace queries over every conv geometry family plus the validation branches of every entry point.  (GPU ASan is not
+    available on this pool; the device code is covered by the -m gpu parity suite.)"""
+    from mri_epilepsy_diagnosis_amd import build as B
+    exe = B.build_host_sanitizer(verbose=False)
+    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=1:halt_on_error=1", UBSAN_OPTIONS="halt_on_error=1:print_stacktrace=1")
+    res = subprocess.run([exe], capture_output=True, text=True, timeout=600, env=env)
+    assert res.returncode == 0, res.stderr[-3000:]
+    assert "AddressSanitizer" not in res.stderr and "runtime error" not in res.stderr, res.stderr[-3000:]
+    assert "ran clean" in res.stdout

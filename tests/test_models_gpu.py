@@ -602,3 +602,95 @@ def test_bench_gpus_2_self_launches_two_ranks_on_one_gpu():
     assert len(lines) == 1, res.stdout
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["ranks_seen"] == 2 and out["config"]["global_batch"] == 4 and out["value"] > 0
+
+
+# ------------------------------------------------------------------------------------------------ routines capture by default
+def _clone_model(m):
+    c = copy.deepcopy(m)
+    if hasattr(c, "_mri3d_step_cache"):
+        object.__delattr__(c, "_mri3d_step_cache")
+    return c
+
+
+def test_run_epoch_captured_by_default_equals_the_eager_loop_bit_for_bit():
+    """segmentation.routine.run_epoch replays a captured hipGraph per batch shape (parallel.StepCache); a twin model whose cache
+    is disabled runs the reference order eagerly.  Losses, parameters, BatchNorm running statistics and num_batches_tracked
+    must be IDENTICAL after train + validate epochs with two alternating batch shapes (same kernels, deterministic reductions;
+    the capture's warm-up runs leave no trace)."""
+    torch.manual_seed(0)
+    a = _unet(8).to(DEV)
+    b = _clone_model(a)
+    shapes = [(1, 1, 32, 32, 32), (2, 1, 16, 32, 16), (1, 1, 32, 32, 32), (2, 1, 16, 32, 16), (1, 1, 32, 32, 32)]
+    batches = [{routine.MRI: {routine.DATA: seeded_randn(90 + i, s)},
+                routine.LABEL: {routine.DATA: (seeded_rand(95 + i, s) < 0.2).float()}} for i, s in enumerate(shapes)]
+    oa, ob = torch.optim.AdamW(a.parameters()), torch.optim.AdamW(b.parameters())
+    parallel.StepCache.of(b).disabled = True
+    la = routine.run_epoch(1, routine.Action.TRAIN, batches, a, oa)
+    lb = routine.run_epoch(1, routine.Action.TRAIN, batches, b, ob)
+    va = routine.run_epoch(1, routine.Action.VALIDATE, batches[:2], a, oa)
+    vb = routine.run_epoch(1, routine.Action.VALIDATE, batches[:2], b, ob)
+    ca, cb = parallel.StepCache.of(a), parallel.StepCache.of(b)
+    assert ca.captures == 4 and ca.replays == 7 and ca.eager_runs == 0      # 2 shapes x (train, validate)
+    assert cb.captures == 0 and cb.eager_runs == 7
+    assert np.array_equal(la, lb) and np.array_equal(va, vb)
+    for (k, x), (_, y) in zip(a.state_dict().items(), b.state_dict().items()):
+        assert torch.equal(x, y), k
+    assert int(a.encoder.encoding_blocks[0].conv2.norm_layer.num_batches_tracked) == 5
+
+
+def test_classification_run_one_epoch_captured_equals_eager_on_the_autoencoder_encoder():
+    """classification.routine.run_one_epoch (a12) with the separable-conv encoder + head: captured replay == eager loop."""
+    kw = dict(CLF_KWARGS, conv_pad=1, l_in=64, p_drop=0.0)
+
+    class Net(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.enc, self.clf = P_AE.AE(**AE_KWARGS_93_6_4).enc, P_AE.Classificator(**kw)
+
+        def forward(self, x):
+            return self.clf(self.enc(x)[0])
+
+    torch.manual_seed(0)
+    a = Net().to(DEV)
+    b = _clone_model(a)
+    parallel.StepCache.of(b).disabled = True
+    g = torch.Generator().manual_seed(4)
+    loader = [(torch.randn(4, 1, 64, 64, 64, generator=g), torch.tensor([0, 1, 1, 0]), torch.arange(4)) for _ in range(3)]
+    res = []
+    for m in (a, b):
+        opt = torch.optim.Adam(m.parameters(), 1e-3, weight_decay=0.01)
+        sch = torch.optim.lr_scheduler.ReduceLROnPlateau(opt, mode="min", factor=0.5, patience=2, threshold=0.001)
+        res.append(clf_routine.run_one_epoch(m, loader, torch.nn.CrossEntropyLoss(), True, DEV, opt, sch, False))
+        with torch.no_grad():
+            res[-1] += clf_routine.run_one_epoch(m, loader[:1], torch.nn.CrossEntropyLoss(), False, DEV, opt, sch, False)
+    assert parallel.StepCache.of(a).captures == 2 and parallel.StepCache.of(a).eager_runs == 0
+    for x, y in zip(res[0], res[1]):
+        assert np.array_equal(np.asarray(x, dtype=np.float64), np.asarray(y, dtype=np.float64))
+    for (k, x), (_, y) in zip(a.state_dict().items(), b.state_dict().items()):
+        assert torch.equal(x, y), k
+
+
+def test_step_cache_replay_matches_eager_for_the_full_autoencoder_and_modified3dunet():
+    """Graph-vs-eager bit equality beyond the U-Net (VERDICT r1 #7): the full AE (MSE) and Modified3DUNet in eval mode."""
+    for make, shape, loss in ((lambda: P_AE.AE(**AE_KWARGS_93_6_4), (2, 1, 64, 64, 64), lambda o, t: F.mse_loss(o, t)),
+                              (lambda: Modified3DUNet(1, 2, 8), (1, 1, 32, 32, 32), lambda o, t: o.float().square().mean())):
+        torch.manual_seed(0)
+        a = make().to(DEV)
+        b = _clone_model(a)
+        if isinstance(a, Modified3DUNet):
+            a.eval(), b.eval()                                  # dropout off: the two copies see the same arithmetic
+        x = seeded_randn(77, shape).to(DEV)
+        ca, cb = parallel.StepCache.of(a), parallel.StepCache.of(b)
+        cb.disabled = True
+        for it in range(3):
+            xi = x * (1.0 + 0.1 * it)
+            oa, la = ca.run(xi, xi, loss, backward=True)
+            oa, la = (oa[0] if isinstance(oa, tuple) else oa).clone(), la.clone()
+            for p in b.parameters():
+                p.grad = None
+            ob, lb = cb.run(xi, xi, loss, backward=True)
+            ob = ob[0] if isinstance(ob, tuple) else ob
+            assert torch.equal(oa, ob) and torch.equal(la, lb)
+            for (k, pa), pb in zip(a.named_parameters(), b.parameters()):
+                assert torch.equal(pa.grad, pb.grad), k
+        assert ca.captures == 1 and ca.replays == 3
