@@ -63,6 +63,14 @@ size_t mri3d_conv3d_workspace_bytes(const Mri3dConvGeom* g, int pass);
 int mri3d_conv3d_fwd(const Mri3dConvGeom* g, const void* x, const void* w, const void* bias, void* y,
                      void* workspace, size_t ws_bytes, mri3d_stream_t stream);
 /* dx = conv_transpose(dy, w) (+ bias, used when this is the forward of a ConvTranspose3d). dx has pitch x_ld. */
+/* Forward convolution that ALSO accumulates the BatchNorm batch statistics of its output (torch.nn.BatchNorm3d in training
+ * mode right after torch.nn.Conv3d: `unet.UNet`'s ConvolutionalBlock; segmentation/routine.py:258 -> unet forward): per output
+ * channel sum(a) and sum(a^2) of the result a WITHOUT its bias over all N x D x H x W voxels, as float64 partials
+ * stat_partials[blocks][co][2] (caller-owned, blocks = mri3d_conv3d_fwd_stats_blocks(g); 0 = geometry not supported, use
+ * mri3d_conv3d_fwd + mri3d_norm_stats).  mri3d_norm_stats_from_partials turns them into mean / invstd (shift = bias). */
+int32_t mri3d_conv3d_fwd_stats_blocks(const Mri3dConvGeom* g);
+int mri3d_conv3d_fwd_stats(const Mri3dConvGeom* g, const void* x, const void* w, const void* bias, void* y,
+                           double* stat_partials, void* workspace, size_t ws_bytes, mri3d_stream_t stream);
 int mri3d_conv3d_dgrad(const Mri3dConvGeom* g, const void* dy, const void* w, const void* bias, void* dx,
                        void* workspace, size_t ws_bytes, mri3d_stream_t stream);
 /* dw (torch layout) = sum_v x (*) dy ; dbias = sum_v dy (dbias may be NULL). */
@@ -99,6 +107,12 @@ size_t mri3d_norm_workspace_bytes(const Mri3dNormGeom* g);
 int mri3d_norm_stats(const Mri3dNormGeom* g, const void* x, float* mean, float* invstd,
                      float* running_mean, float* running_var, float momentum,
                      void* workspace, size_t ws_bytes, mri3d_stream_t stream);
+/* mean / invstd (and the running-statistics update of mri3d_norm_stats) from float64 partial sums
+ * partials[nblk][c][2] = (sum(x - shift[c]), sum((x - shift[c])^2)) over disjoint parts of the N x vox voxels (batch statistics
+ * only).  shift may be NULL (zero). */
+int mri3d_norm_stats_from_partials(const Mri3dNormGeom* g, const double* partials, int32_t nblk, const float* shift,
+                                   float* mean, float* invstd, float* running_mean, float* running_var, float momentum,
+                                   mri3d_stream_t stream);
 /* y = act(gamma * (x - mean) * invstd + beta).  gamma/beta may be NULL (affine=False); alpha is the
  * PReLU parameter (device pointer) when act == MRI3D_ACT_PRELU.  mean/invstd NULL => identity norm. */
 int mri3d_norm_act_fwd(const Mri3dNormGeom* g, const void* x, const float* mean, const float* invstd,

@@ -32,6 +32,9 @@ int conv_mfma_dgrad(const Mri3dConvGeom& g, const void* dy, const float* w, cons
                     size_t ws_bytes, hipStream_t s);
 int conv_mfma_wgrad(const Mri3dConvGeom& g, const void* x, const void* dy, float* dw, float* dbias, void* ws,
                     size_t ws_bytes, hipStream_t s);
+int conv_mfma_fwd_stat_blocks(const Mri3dConvGeom& g);
+int conv_mfma_fwd_stats(const Mri3dConvGeom& g, const void* x, const float* w, const float* bias, void* y, double* stat_part,
+                        void* ws, size_t ws_bytes, hipStream_t s);
 
 // conv_pointwise.hip
 bool conv_pointwise_supported(const Mri3dConvGeom& g, int pass);
@@ -92,6 +95,22 @@ extern "C" int mri3d_conv3d_fwd(const Mri3dConvGeom* g, const void* x, const voi
     if (conv_mfma_supported(*g, MRI3D_PASS_FWD) && aligned16(x, y, workspace))
         return conv_mfma_fwd(*g, x, (const float*)w, (const float*)bias, y, workspace, ws_bytes, s);
     return conv_generic_fwd(*g, x, (const float*)w, (const float*)bias, y, workspace, ws_bytes, s);
+}
+
+extern "C" int32_t mri3d_conv3d_fwd_stats_blocks(const Mri3dConvGeom* g) {
+    if (!g || conv_check(g, "conv3d_fwd_stats_blocks") != MRI3D_OK) return 0;
+    return conv_mfma_supported(*g, MRI3D_PASS_FWD) ? conv_mfma_fwd_stat_blocks(*g) : 0;
+}
+
+extern "C" int mri3d_conv3d_fwd_stats(const Mri3dConvGeom* g, const void* x, const void* w, const void* bias, void* y,
+                                      double* stat_partials, void* workspace, size_t ws_bytes, mri3d_stream_t stream) {
+    int rc = conv_check(g, "conv3d_fwd_stats");
+    if (rc) return rc;
+    MRI3D_REQUIRE(x && w && y && stat_partials, MRI3D_EINVAL, "conv3d_fwd_stats: null pointer");
+    MRI3D_REQUIRE(conv_mfma_supported(*g, MRI3D_PASS_FWD) && conv_mfma_fwd_stat_blocks(*g) > 0 && aligned16(x, y, workspace),
+                  MRI3D_ENOTSUP, "conv3d_fwd_stats: geometry not served by the MFMA forward kernel (query mri3d_conv3d_fwd_stats_blocks)");
+    return conv_mfma_fwd_stats(*g, x, (const float*)w, (const float*)bias, y, stat_partials, workspace, ws_bytes,
+                               static_cast<hipStream_t>(stream));
 }
 
 extern "C" int mri3d_conv3d_dgrad(const Mri3dConvGeom* g, const void* dy, const void* w, const void* bias, void* dx,

@@ -127,11 +127,25 @@ constexpr int kStg = (HVOX * 2 + 255) / 256;  // 16-byte staging pieces per lane
 // slice = 16 channels, 16-byte pieces, identical staging and LDS addressing) with one v_mfma_f32_16x16x32_bf16 per tap
 // group; the kernel is then bound by the LDS operand reads (the bf16 3x3x3 layers are memory-bound).
 // `wp` is the packed weight image (fp32 or bf16), addressed in 16-byte fragments.
-template <typename T, int NT>
+// sum over the 16 lanes of a DPP row (lanes with equal lane >> 4): four row rotations, every lane ends with the total
+__device__ __forceinline__ float row_sum16(float v) {
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x128, 0xf, 0xf, false));   // row_ror:8
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x124, 0xf, 0xf, false));   // row_ror:4
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x122, 0xf, 0xf, false));   // row_ror:2
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x121, 0xf, 0xf, false));   // row_ror:1
+    return v;
+}
+
+// STATS (forward only): the epilogue also accumulates, per output channel, sum(a) and sum(a^2) of the convolution result a
+// WITHOUT its bias over the voxels of the volume — the BatchNorm batch statistics of y = a + bias (shift = bias), so that the
+// statistics pass over y (one full read of every conv output, 0.5 ms per step of the U-Net) is not needed.  fp32 over a wave's
+// 8 x 16 voxels of a tile, float64 from there on: per wave in LDS, one partial per workgroup in `stat_part`
+// [gridDim.x][Nc][2], summed in a fixed order by norm_stats_finalize_kernel (deterministic: the tile -> workgroup map is static).
+template <typename T, int NT, bool STATS>
 __global__ void __launch_bounds__(256, 2)
 conv_mfma_fwd2_kernel(const T* __restrict__ x, const float* __restrict__ wp, const float* __restrict__ bias,
                       T* __restrict__ y, int N, int D, int H, int W, int Kc, int x_ld, int Nc, int y_ld, int NTT,
-                      int gy, int tilesD, int tilesH, int tilesW, int ntiles) {
+                      int gy, int tilesD, int tilesH, int tilesW, int ntiles, double* __restrict__ stat_part) {
     constexpr bool kBf16 = sizeof(T) == 2;
     constexpr int CK = 32 / sizeof(T);   // channels per 32-byte chunk (8 fp32 / 16 bf16)
     constexpr int PE = 16 / sizeof(T);   // channels per 16-byte piece
@@ -152,6 +166,14 @@ conv_mfma_fwd2_kernel(const T* __restrict__ x, const float* __restrict__ wp, con
     const int r_lo = (int)(((int64_t)ntiles * xcd) / NX), r_hi = (int)(((int64_t)ntiles * (xcd + 1)) / NX);
     const int my_tiles = (r_hi - r_lo - wslot + wper - 1) / wper;      // tiles r_lo + wslot + k * wper < r_hi
     const int nitems = (r_lo + wslot < r_hi ? my_tiles : 0) * nchunks;
+    double* const stat_lds = reinterpret_cast<double*>(lds + 2 * BUF);   // [4 waves][NTT * 16 channels][2]
+    if constexpr (STATS) {
+        if (nitems <= 0) {   // a workgroup without tiles still owns a partial: zeros
+            for (int i = tid; i < Nc * 2; i += 256) stat_part[(size_t)blockIdx.x * Nc * 2 + i] = 0.0;
+            return;
+        }
+        for (int i = tid; i < 4 * NTT * 16 * 2; i += 256) stat_lds[i] = 0.0;   // visible after the prologue's barrier
+    }
     if (nitems <= 0) return;
 
     // per-lane staging geometry (independent of the item): piece j covers halo voxel (j*256+tid)>>1, channel quad &1
@@ -397,6 +419,36 @@ conv_mfma_fwd2_kernel(const T* __restrict__ x, const float* __restrict__ wp, con
                     }
                 }
             }
+            if constexpr (STATS) {
+                const bool vok = cur.d0 + wv < D && cur.w0 + li < W;
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                    float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int m = 0; m < TH; ++m) {
+                        const bool ok = vok && cur.h0 + m < H;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const float a = ok ? acc[m][nt][r] : 0.f;
+                            s1[r] += a;
+                            s2[r] += a * a;
+                        }
+                    }
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        s1[r] = row_sum16(s1[r]);
+                        s2[r] = row_sum16(s2[r]);
+                    }
+                    if (li == 0) {   // one lane per k-group: channels 4*kq .. 4*kq+3 of this N-tile, this wave's own LDS slot
+                        double* slot = stat_lds + ((size_t)wv * NTT * 16 + (cur.nt0 + nt) * 16 + 4 * kq) * 2;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            slot[2 * r] += (double)s1[r];
+                            slot[2 * r + 1] += (double)s2[r];
+                        }
+                    }
+                }
+            }
 #pragma unroll
             for (int m = 0; m < TH; ++m)
 #pragma unroll
@@ -405,12 +457,21 @@ conv_mfma_fwd2_kernel(const T* __restrict__ x, const float* __restrict__ wp, con
         __syncthreads();  // buffer (it+1)&1 is complete; buffer it&1 may be overwritten from the next iteration on
         cur = nxt;
     }
+    if constexpr (STATS) {   // the loop ended with a barrier: combine the four waves in a fixed order, one partial per workgroup
+        for (int i = tid; i < Nc * 2; i += 256) {
+            const int c2 = i;   // (channel, stat) pair; LDS rows are NTT*16 channels wide
+            double v = 0.0;
+#pragma unroll
+            for (int w4 = 0; w4 < 4; ++w4) v += stat_lds[(size_t)w4 * NTT * 16 * 2 + c2];
+            stat_part[(size_t)blockIdx.x * Nc * 2 + i] = v;
+        }
+    }
 }
 
 // ------------------------------------------------------------------ host side
 struct MfmaFwdPlan {
     int CK, NT, NTT, gy, nchunks, tilesD, tilesH, tilesW, ntiles, grid;
-    size_t wp_floats, smem;
+    size_t wp_floats, smem, stat_smem;
 };
 
 static bool mfma_fwd_plan(const Mri3dConvGeom& g, bool dgrad, MfmaFwdPlan& p) {
@@ -437,6 +498,7 @@ static bool mfma_fwd_plan(const Mri3dConvGeom& g, bool dgrad, MfmaFwdPlan& p) {
     p.ntiles = (int)nt;
     p.wp_floats = (size_t)p.nchunks * 14 * p.NTT * 256;   // 1 KiB per (chunk, tap group, N-tile)
     p.smem = (size_t)2 * kStg * 256 * 16;
+    p.stat_smem = (size_t)4 * p.NTT * 16 * 2 * sizeof(double);   // per-wave float64 statistics of the STATS variant
     int64_t st = (int64_t)p.ntiles * p.gy;  // (spatial tile, n-tile block) work units
     if (st > 0x7fffffff) return false;
     p.grid = (int)std::min<int64_t>(st, 512);  // 2 resident workgroups per CU x 256 CUs
@@ -444,7 +506,7 @@ static bool mfma_fwd_plan(const Mri3dConvGeom& g, bool dgrad, MfmaFwdPlan& p) {
 }
 
 static int run_mfma_fwd(const Mri3dConvGeom& g, bool dgrad, const void* in_v, const float* w, const float* bias,
-                        void* out_v, void* ws, size_t ws_bytes, hipStream_t s) {
+                        void* out_v, void* ws, size_t ws_bytes, hipStream_t s, double* stat_part = nullptr) {
     MfmaFwdPlan p;
     MRI3D_REQUIRE(mfma_fwd_plan(g, dgrad, p), MRI3D_ENOTSUP, "conv3d(mfma): unsupported geometry");
     MRI3D_REQUIRE(ws && ws_bytes >= p.wp_floats * sizeof(float), MRI3D_EWORKSPACE, "conv3d(mfma): workspace %zu < %zu",
@@ -462,19 +524,24 @@ static int run_mfma_fwd(const Mri3dConvGeom& g, bool dgrad, const void* in_v, co
         hipLaunchKernelGGL(pack_w_mfma_kernel, dim3(std::min(cdiv(total, 256), 2048)), dim3(256), 0, s, w, wp, g.co, g.ci,
                            dgrad ? 1 : 0, 8, p.NTT, p.nchunks);
     const int st = p.ntiles * p.gy;
-    const size_t smem = p.smem;
-#define MRI3D_FWD2_CASE(NTv)                                                                                          \
-    if (p.NT == NTv) {                                                                                                \
-        auto kern = conv_mfma_fwd2_kernel<T, NTv>;                                                                    \
+    const size_t smem = p.smem + (stat_part ? p.stat_smem : 0);
+    constexpr int kMaxSmem = 2 * kStg * 256 * 16 + 4 * 8 * 16 * 2 * 8;   // two halo buffers + float64 statistics of up to 128 channels
+    MRI3D_REQUIRE(smem <= (size_t)kMaxSmem, MRI3D_ENOTSUP, "conv3d(mfma): too many output channels for fused statistics");
+#define MRI3D_FWD2_CASE(NTv, STv)                                                                                     \
+    if (p.NT == NTv && (stat_part != nullptr) == STv) {                                                               \
+        auto kern = conv_mfma_fwd2_kernel<T, NTv, STv>;                                                               \
         static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),                       \
-                                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);    \
+                                                           hipFuncAttributeMaxDynamicSharedMemorySize, kMaxSmem);     \
         (void)attr;   /* once per kernel, not per launch */                                                          \
         hipLaunchKernelGGL(kern, dim3(p.grid), dim3(256), smem, s, (const T*)in_v, wp, bias, (T*)out_v, g.n, g.di,    \
-                           g.hi, g.wi, Kc, in_ld, Nc, out_ld, p.NTT, p.gy, p.tilesD, p.tilesH, p.tilesW, st);        \
+                           g.hi, g.wi, Kc, in_ld, Nc, out_ld, p.NTT, p.gy, p.tilesD, p.tilesH, p.tilesW, st,         \
+                           stat_part);                                                                                \
     }
     MRI3D_DISPATCH_DTYPE(g.dtype, T, {
-        MRI3D_FWD2_CASE(1)
-        MRI3D_FWD2_CASE(2)
+        MRI3D_FWD2_CASE(1, false)
+        MRI3D_FWD2_CASE(2, false)
+        MRI3D_FWD2_CASE(1, true)
+        MRI3D_FWD2_CASE(2, true)
     });
 #undef MRI3D_FWD2_CASE
     return check_launch(dgrad ? "conv3d_dgrad(mfma)" : "conv3d_fwd(mfma)");
@@ -483,6 +550,19 @@ static int run_mfma_fwd(const Mri3dConvGeom& g, bool dgrad, const void* in_v, co
 int conv_mfma_fwd(const Mri3dConvGeom& g, const void* x, const float* w, const float* bias, void* y, void* ws,
                   size_t ws_bytes, hipStream_t s) {
     return run_mfma_fwd(g, false, x, w, bias, y, ws, ws_bytes, s);
+}
+
+// number of per-workgroup statistics partials the forward kernel writes for this geometry (0: not served by the MFMA path)
+int conv_mfma_fwd_stat_blocks(const Mri3dConvGeom& g) {
+    MfmaFwdPlan p;
+    if (!mfma_fwd_plan(g, false, p) || p.NTT > 8) return 0;   // LDS statistics slots for up to 128 output channels
+    return p.grid;
+}
+
+int conv_mfma_fwd_stats(const Mri3dConvGeom& g, const void* x, const float* w, const float* bias, void* y, double* stat_part,
+                        void* ws, size_t ws_bytes, hipStream_t s) {
+    MRI3D_REQUIRE(stat_part != nullptr, MRI3D_EINVAL, "conv3d_fwd_stats: null partial buffer");
+    return run_mfma_fwd(g, false, x, w, bias, y, ws, ws_bytes, s, stat_part);
 }
 
 int conv_mfma_dgrad(const Mri3dConvGeom& g, const void* dy, const float* w, const float* bias, void* dx, void* ws,
@@ -991,24 +1071,33 @@ conv_mfma_wgrad4_kernel(const T* __restrict__ x, const T* __restrict__ dy, float
     for (int i = tid; i < TGA * 256; i += 256) out[i] = red[i];
 }
 
-// ------------------------------------------------------------------ weight gradient on the bf16 MFMA (bf16 tensors)
-// v_mfma_f32_16x16x32_bf16 sums over K = 32 VOXELS, and a lane's operand is 8 CONSECUTIVE k: the NDHWC tile has to be
-// transposed to [channel][voxel] on its way into LDS.  A workgroup stages a 2x6x32-voxel tile:
-//   X halo: 4 x 8 rows of (32 voxels + the two W-halo voxels) for the 16 input channels of its ci-tile,
-//   dY:     2 x 6 rows of 32 voxels for the 16 output channels of its co-tile,
-// each lane loading 8 consecutive voxels x 8 channels (8 x 16 B) and transposing them in registers (v_perm) into eight
-// 16-byte LDS writes.  A (row, channel) line is 64 B of voxels + 16 B of padding whose first dword holds the two halo
-// voxels (lo = voxel 32, hi = voxel -1); the 80-byte pitch makes the 16-lane ds_read_b128 of 16 channels conflict-free.
-// The kw = 0 / 2 taps are the same 32 voxels shifted by one: they are built from the aligned fragment and its two
-// neighbour dwords with v_alignbyte instead of extra LDS traffic (1 b128 + 2 b32 reads feed 3 MFMAs).
-// Accumulators: 27 taps x (16 ci x 16 co) per wave (+1 for dbias, fed with A = 1), same partial layout as v4.
+// ------------------------------------------------------------------ weight gradient, transposed tiles (bf16 MFMA and fp32 v6)
+// Both kernels below keep the tile TRANSPOSED in LDS, [channel][voxel]: the MFMA sums over voxels, and a lane's operand is a run
+// of consecutive voxels of one channel.  Tile = 2 x 6 rows of TW voxels (TW = 32 bf16 / 16 fp32); X needs its (kd, kh) halo
+// rows (4 x 8 rows), dY its 12 output rows.
+//
+// The kw taps:  dW[kd,kh,kw] = sum_v X[v + kw - 1] dY[v]  =  sum_u X[u] dY[u + 1 - kw].  The shift is applied to dY, not to X:
+// per output row the three fragments dY[u+1], dY[u], dY[u-1] are built ONCE (register selection / v_alignbyte from the aligned
+// fragment and its two neighbour voxels) and every (kd, kh) then costs ONE aligned X read for three MFMAs.  (Round 1 shifted X:
+// one aligned read plus two neighbour reads per (kd, kh), 3-way bank-conflicted — PMC: SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE =
+// 0.64 in the bf16 kernel, which was LDS-bound at 18 % MFMA busy.)  The sums are re-partitioned between W-neighbouring tiles —
+// a tile now takes the products of ITS X voxels, with dY[w0-1] and dY[w0+TW] read from the neighbours (zero outside the volume)
+// — so X has no W halo at all and dY has a one-voxel W halo; the total over tiles is unchanged.
+//
+// LDS image: a (row, channel) line is 64 bytes = four 16-byte slots; logical slot q of channel c sits at physical slot
+// (q + 2*(c >> 3)) & 3.  The hardware serves a ds_read_b128 in the lane groups {0-3,12-15,20-27}, {4-11,16-19,28-31}, ...
+// (MI355X_MICROARCH.md §LDS), i.e. channels 4..11 of a group read the NEXT k-group's slot; with unpadded 64-byte lines and the
+// two-slot rotation of channels 8..15 all 16 lanes of every group hit different 4-bank slots (the 80-byte padded lines of round
+// 1 cost 8 instead of 4 LDS cycles per read).
 constexpr int BTD = 2, BTH = 6, BTW = 32;
 constexpr int BHD = BTD + 2, BHH = BTH + 2;
 constexpr int BXR = BHD * BHH;            // 32 X rows
 constexpr int BYR = BTD * BTH;            // 12 dY rows
-constexpr int BRS = 80;                   // bytes per (row, channel) line
-constexpr int BXS = BXR * 16 * BRS;       // 40960 B
-constexpr int BYS = BYR * 16 * BRS;       // 15360 B
+constexpr int DLS = 64;                   // bytes per (row, channel) line
+constexpr int BXS = BXR * 16 * DLS;       // 32768 B  X
+constexpr int BYS = BYR * 16 * DLS;       // 12288 B  dY
+constexpr int BYH = BYR * 16 * 8;         //  1536 B  dY W-halo: per line {dword holding dY[w0-1], dword holding dY[w0+TW]}
+__device__ __forceinline__ int rot_slot(int q, int c) { return (q + 2 * ((c >> 3) & 1)) & 3; }
 
 // eight voxels x eight channels (v[j] = the 16-byte channel vector of voxel j) -> out[c] = the 8 voxels of channel c
 __device__ __forceinline__ void transpose8x8_bf16(const uint4 (&v)[8], uint4 (&out)[8]) {
@@ -1031,6 +1120,9 @@ __device__ __forceinline__ uint4 ldg4u(const bf16_t* p) {
     return make_uint4(v[0], v[1], v[2], v[3]);
 }
 
+// v_mfma_f32_16x16x32_bf16 sums over K = 32 VOXELS with 8 consecutive k per lane.  Staging: each lane loads 8 consecutive
+// voxels x 8 channels (8 x 16 B) and transposes them in registers (v_perm) into eight 16-byte LDS writes.
+// Accumulators: 27 taps x (16 ci x 16 co) per wave (+1 for dbias, fed with A = 1).
 template <bool BIAS>
 __global__ void __launch_bounds__(256, 2)
 conv_mfma_wgrad_bf16_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ dy, float* __restrict__ part, int N,
@@ -1040,6 +1132,7 @@ conv_mfma_wgrad_bf16_kernel(const bf16_t* __restrict__ x, const bf16_t* __restri
     extern __shared__ __attribute__((aligned(16))) float lds[];
     char* xs = reinterpret_cast<char*>(lds);
     char* ys = xs + BXS;
+    char* yh = ys + BYS;
 
     const int cit = blockIdx.y, cob = blockIdx.z;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -1051,103 +1144,146 @@ conv_mfma_wgrad_bf16_kernel(const bf16_t* __restrict__ x, const bf16_t* __restri
 
     // staging roles (fixed per lane)
     const int s_half = tid & 1, s_wg = (tid >> 1) & 3, s_row = tid >> 3;     // X: 32 rows x 4 w-groups x 2 channel halves
-    const int h_half = tid & 1, h_side = (tid >> 1) & 1, h_row = tid >> 2;   // X halo voxels (tid < 128)
+    const int h_half = tid & 1, h_side = (tid >> 1) & 1;   // dY halo voxels (lanes 128 .. 175)
     const uint4 zero4 = make_uint4(0u, 0u, 0u, 0u);
-    // per-lane operand offsets
-    const int p_off = kq == 0 ? 64 : 16 * kq - 4, n_off = kq == 3 ? 64 : 16 * kq + 16;
+    // per-lane operand addresses
     const int orow0 = wv * (BYR / 4);   // first of the wave's three output rows (same d-plane, consecutive h)
-    const char* const xrow0 = xs + (((orow0 / BTH) * BHH + orow0 % BTH) * 16 + li) * BRS;
-    const char* const yrow0 = ys + (orow0 * 16 + li) * BRS + 16 * kq;
+    const char* const xrow0 = xs + (((orow0 / BTH) * BHH + orow0 % BTH) * 16 + li) * DLS + 16 * rot_slot(kq, li);
+    const int yline0 = orow0 * 16 + li;
+    const char* const yrow0 = ys + yline0 * DLS + 16 * rot_slot(kq, li);
+    // the dword holding the voxel before / after the lane's eight: last dword of the previous / first dword of the next k-group's
+    // slot, or the W-halo entry of the line (k-groups 0 and 3)
+    const char* const ypl0 = kq == 0 ? yh + yline0 * 8 : ys + yline0 * DLS + 16 * rot_slot(kq - 1, li) + 12;
+    const char* const ynr0 = kq == 3 ? yh + yline0 * 8 + 4 : ys + yline0 * DLS + 16 * rot_slot(kq + 1, li);
+    const int pl_step = kq == 0 ? 16 * 8 : 16 * DLS, nr_step = kq == 3 ? 16 * 8 : 16 * DLS;
     bf16x8_t ones;
 #pragma unroll
     for (int i = 0; i < 8; ++i) ones[i] = (bf16_t)1.0f;
 
-    const TileWalk tw = tile_walk(ntiles);
-    for (int k = 0; k < tw.count; ++k) {
-        int tile = tw.first + k * tw.stride;
+    // The next tile's pieces are fetched into registers while the current tile is multiplied and transposed / written to the single
+    // LDS tile between two barriers after it (as in wgrad6): the HBM latency of a tile is no longer exposed in front of its MFMAs
+    // (round 1 staged synchronously: 18 % MFMA busy).
+    uint4 vx[8], vy[8];
+    uint4& vh = vy[0];   // the halo lanes (128 .. 175) stage no dY rows: their one piece shares a register with them
+    const bool is_y = tid < BYR * 8, is_h = tid >= 128 && tid < 128 + BYR * 4;
+    const int hy_row = (tid - 128) >> 2;   // dY halo row of lanes 128 .. 175
+    // per-lane byte-free element offsets from the tile's origin voxels (X: (d0-1, h0-1, w0); dY: (d0, h0, w0); halo: (d0, h0, w0-1))
+    const unsigned xrel = (unsigned)((((s_row / BHH) * H + s_row % BHH) * W + 8 * s_wg) * x_ld + 8 * s_half);
+    const unsigned yrel = (unsigned)((((s_row / BTH) * H + s_row % BTH) * W + 8 * s_wg) * y_ld + 8 * s_half);
+    const unsigned hrel = (unsigned)((((hy_row / BTH) * H + hy_row % BTH) * W + (h_side ? BTW + 1 : 0)) * y_ld + 8 * h_half);
+    const bool ch_full = cit * 16 + 16 <= Ci && cob * 16 + 16 <= Co;
+    auto load_tile = [&](int tile) {
         const int w0 = (tile % tilesW) * BTW;
         tile /= tilesW;
         const int h0 = (tile % tilesH) * BTH;
         tile /= tilesH;
         const int d0 = (tile % tilesD) * BTD;
         const int n = tile / tilesD;
-
-        __syncthreads();   // the previous tile's MFMAs are done with the buffers
+        if (d0 >= 1 && d0 + BTD < D && h0 >= 1 && h0 + BTH < H && w0 >= 1 && w0 + BTW < W && ch_full) {
+            // interior tile (wave-uniform): scalar bases + precomputed lane offsets, no coordinates, no masks
+            const bf16_t* xb = x + ((((int64_t)n * D + d0 - 1) * H + h0 - 1) * W + w0) * x_ld + cit * 16;
+            const bf16_t* yb = dy + ((((int64_t)n * D + d0) * H + h0) * W + w0) * y_ld + cob * 16;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) vx[j] = ldg4u(xb + j * x_ld + xrel);
+            if (is_y) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) vy[j] = ldg4u(yb + j * y_ld + yrel);
+            }
+            if (is_h) vh = ldg4u(yb - y_ld + hrel);
+            return;
+        }
         {   // ---- X: 8 voxels x 8 channels per lane
             const int gd = d0 - 1 + s_row / BHH, gh = h0 - 1 + s_row % BHH;
             const int c0 = cit * 16 + 8 * s_half;
             const bool rok = (unsigned)gd < (unsigned)D && (unsigned)gh < (unsigned)H && c0 < Ci;
             const bf16_t* src = x + ((((int64_t)n * D + (rok ? gd : 0)) * H + (rok ? gh : 0)) * W) * x_ld + (c0 < Ci ? c0 : 0);
-            uint4 v[8], o[8];
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 const int gw = w0 + 8 * s_wg + j;
                 const uint4 t = ldg4u(src + (int64_t)min(gw, W - 1) * x_ld);   // unconditional, explicitly global (see wgrad6)
-                v[j] = (rok && gw < W) ? t : zero4;
-            }
-            transpose8x8_bf16(v, o);
-#pragma unroll
-            for (int c = 0; c < 8; ++c)
-                *reinterpret_cast<uint4*>(xs + (s_row * 16 + 8 * s_half + c) * BRS + 16 * s_wg) = o[c];
-        }
-        if (tid < 128) {   // ---- X halo voxels w0-1 (hi half) and w0+32 (lo half)
-            const int gd = d0 - 1 + h_row / BHH, gh = h0 - 1 + h_row % BHH, gw = h_side ? w0 + BTW : w0 - 1;
-            const int c0 = cit * 16 + 8 * h_half;
-            const bool ok = (unsigned)gd < (unsigned)D && (unsigned)gh < (unsigned)H && (unsigned)gw < (unsigned)W && c0 < Ci;
-            const uint4 ht = ldg4u(x + ((((int64_t)n * D + (ok ? gd : 0)) * H + (ok ? gh : 0)) * W + (ok ? gw : 0)) * x_ld + (c0 < Ci ? c0 : 0));
-            const uint4 hv = ok ? ht : zero4;
-            const unsigned* hw = reinterpret_cast<const unsigned*>(&hv);
-#pragma unroll
-            for (int c = 0; c < 8; ++c) {
-                const unsigned short val = (unsigned short)((c & 1) ? (hw[c >> 1] >> 16) : (hw[c >> 1] & 0xffffu));
-                *reinterpret_cast<unsigned short*>(xs + (h_row * 16 + 8 * h_half + c) * BRS + 64 + (h_side ? 0 : 2)) = val;
+                vx[j] = (rok && gw < W) ? t : zero4;
             }
         }
-        if (tid < BYR * 8) {   // ---- dY: 12 rows x 4 w-groups x 2 channel halves
+        if (is_y) {   // ---- dY: 12 rows x 4 w-groups x 2 channel halves
             const int gd = d0 + s_row / BTH, gh = h0 + s_row % BTH;
             const int c0 = cob * 16 + 8 * s_half;
             const bool rok = gd < D && gh < H && c0 < Co;       // host guarantees Co % 8 == 0
             const bf16_t* src = dy + ((((int64_t)n * D + (rok ? gd : 0)) * H + (rok ? gh : 0)) * W) * y_ld + (c0 < Co ? c0 : 0);
-            uint4 v[8], o[8];
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 const int gw = w0 + 8 * s_wg + j;
                 const uint4 t = ldg4u(src + (int64_t)min(gw, W - 1) * y_ld);
-                v[j] = (rok && gw < W) ? t : zero4;
+                vy[j] = (rok && gw < W) ? t : zero4;
             }
-            transpose8x8_bf16(v, o);
-#pragma unroll
-            for (int c = 0; c < 8; ++c)
-                *reinterpret_cast<uint4*>(ys + (s_row * 16 + 8 * s_half + c) * BRS + 16 * s_wg) = o[c];
         }
+        if (is_h) {   // ---- dY W-halo voxels w0 - 1 and w0 + 32
+            const int gd = d0 + hy_row / BTH, gh = h0 + hy_row % BTH, gw = h_side ? w0 + BTW : w0 - 1;
+            const int c0 = cob * 16 + 8 * h_half;
+            const bool ok = gd < D && gh < H && (unsigned)gw < (unsigned)W && c0 < Co;
+            const uint4 ht = ldg4u(dy + ((((int64_t)n * D + (ok ? gd : 0)) * H + (ok ? gh : 0)) * W + (ok ? gw : 0)) * y_ld + (c0 < Co ? c0 : 0));
+            vh = ok ? ht : zero4;
+        }
+    };
+    auto store_tile = [&]() {
+        uint4 o[8];
+        transpose8x8_bf16(vx, o);
+        char* dline = xs + (s_row * 16 + 8 * s_half) * DLS + 16 * rot_slot(s_wg, 8 * s_half);   // 8 channels share a rotation
+#pragma unroll
+        for (int c = 0; c < 8; ++c) *reinterpret_cast<uint4*>(dline + c * DLS) = o[c];
+        if (is_y) {
+            transpose8x8_bf16(vy, o);
+            char* yline = ys + (s_row * 16 + 8 * s_half) * DLS + 16 * rot_slot(s_wg, 8 * s_half);
+#pragma unroll
+            for (int c = 0; c < 8; ++c) *reinterpret_cast<uint4*>(yline + c * DLS) = o[c];
+        } else if (is_h) {   // w0 - 1: high half of dword 0;  w0 + 32: low half of dword 1
+            const unsigned* hw = reinterpret_cast<const unsigned*>(&vh);
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                const unsigned short val = (unsigned short)((c & 1) ? (hw[c >> 1] >> 16) : (hw[c >> 1] & 0xffffu));
+                *reinterpret_cast<unsigned short*>(yh + (hy_row * 16 + 8 * h_half + c) * 8 + (h_side ? 4 : 2)) = val;
+            }
+        }
+    };
+
+    const TileWalk tw = tile_walk(ntiles);
+    if (tw.count > 0) load_tile(tw.first);
+    for (int k = 0; k < tw.count; ++k) {
+        __syncthreads();   // the previous tile's MFMAs are done with the LDS tile
+        store_tile();
         __syncthreads();
+        if (k + 1 < tw.count) load_tile(tw.first + (k + 1) * tw.stride);
+        __builtin_amdgcn_sched_barrier(0);
 
         // ---- 3 output rows per wave x 9 (kd, kh) x 3 kw MFMAs
         // the wave's three rows are consecutive in h: constant-stride row pointers, every tap an immediate offset
         const char* xrow = xrow0;
         const char* yrow = yrow0;
+        const char* ypl = ypl0;
+        const char* ynr = ynr0;
 #pragma unroll 1
-        for (int r = 0; r < BYR / 4; ++r, xrow += 16 * BRS, yrow += 16 * BRS) {
-            const bf16x8_t b = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(yrow));
-            if (BIAS) acc[TG] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, b, acc[TG], 0, 0, 0);
+        for (int r = 0; r < BYR / 4; ++r, xrow += 16 * DLS, yrow += 16 * DLS, ypl += pl_step, ynr += nr_step) {
+            const uint4 b1 = *reinterpret_cast<const uint4*>(yrow);            // dY[u], the lane's eight voxels
+            const unsigned pl = *reinterpret_cast<const unsigned*>(ypl);        // high half = dY[first - 1]
+            const unsigned nr = *reinterpret_cast<const unsigned*>(ynr);        // low half = dY[last + 1]
+            uint4 bm, bp;   // dY[u - 1], dY[u + 1]
+            bm.x = __builtin_amdgcn_alignbyte(b1.x, pl, 2);
+            bm.y = __builtin_amdgcn_alignbyte(b1.y, b1.x, 2);
+            bm.z = __builtin_amdgcn_alignbyte(b1.z, b1.y, 2);
+            bm.w = __builtin_amdgcn_alignbyte(b1.w, b1.z, 2);
+            bp.x = bm.y;
+            bp.y = bm.z;
+            bp.z = bm.w;
+            bp.w = __builtin_amdgcn_alignbyte(nr, b1.w, 2);
+            const bf16x8_t b0v = __builtin_bit_cast(bf16x8_t, bp), b1v = __builtin_bit_cast(bf16x8_t, b1),
+                           b2v = __builtin_bit_cast(bf16x8_t, bm);
+            if (BIAS) acc[TG] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, b1v, acc[TG], 0, 0, 0);
 #pragma unroll
             for (int kdh = 0; kdh < 9; ++kdh) {
-                const int loff = ((kdh / 3) * BHH + kdh % 3) * 16 * BRS;   // compile-time after unrolling
-                const uint4 g = *reinterpret_cast<const uint4*>(xrow + 16 * kq + loff);
-                const unsigned pp = *reinterpret_cast<const unsigned*>(xrow + p_off + loff);
-                const unsigned nn = *reinterpret_cast<const unsigned*>(xrow + n_off + loff);
-                uint4 a0, a2;
-                a0.x = __builtin_amdgcn_alignbyte(g.x, pp, 2);
-                a0.y = __builtin_amdgcn_alignbyte(g.y, g.x, 2);
-                a0.z = __builtin_amdgcn_alignbyte(g.z, g.y, 2);
-                a0.w = __builtin_amdgcn_alignbyte(g.w, g.z, 2);
-                a2.x = a0.y;
-                a2.y = a0.z;
-                a2.z = a0.w;
-                a2.w = __builtin_amdgcn_alignbyte(nn, g.w, 2);
-                acc[kdh * 3 + 0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a0), b, acc[kdh * 3 + 0], 0, 0, 0);
-                acc[kdh * 3 + 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, g), b, acc[kdh * 3 + 1], 0, 0, 0);
-                acc[kdh * 3 + 2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a2), b, acc[kdh * 3 + 2], 0, 0, 0);
+                const int lrow = ((kdh / 3) * BHH + kdh % 3) * 16;   // compile-time after unrolling
+                const bf16x8_t g = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(xrow + lrow * DLS));
+                acc[kdh * 3 + 0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(g, b0v, acc[kdh * 3 + 0], 0, 0, 0);   // X[u] dY[u+1]
+                acc[kdh * 3 + 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(g, b1v, acc[kdh * 3 + 1], 0, 0, 0);   // X[u] dY[u]
+                acc[kdh * 3 + 2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(g, b2v, acc[kdh * 3 + 2], 0, 0, 0);   // X[u] dY[u-1]
             }
         }
     }
@@ -1172,13 +1308,12 @@ conv_mfma_wgrad_bf16_kernel(const bf16_t* __restrict__ x, const bf16_t* __restri
 }
 
 // ------------------------------------------------------------------ weight gradient, version 6 (fp32, Cin % 16 == 0)
-// The bf16 kernel's [channel][voxel] LDS tile, for fp32: a (row, channel) line holds 16 voxels (64 B) + the two W-halo
-// voxels, and the MFMA K order is permuted so that k-group kq of the four k-steps of a row owns voxels 4kq..4kq+3 — ONE
-// ds_read_b128 then feeds four v_mfma_f32_16x16x4_f32 k-steps, and the kw = 0 / 2 taps are the same fragment shifted by one
-// voxel, i.e. pure register selection from (left neighbour, fragment, right neighbour).  A 2x6x16-voxel tile costs a wave
-// 3 rows x (1 + 9 x 3) = 84 LDS reads for 324 MFMAs; v4 issues one 4-byte LDS read per MFMA, and every non-MFMA
-// instruction shows up as idle MFMA time (ablation in DESIGN.md §4.1).  Staging transposes 4 voxels x 4 channels per
-// lane by register renaming.  Same accumulators and partial layout as v4.
+// The transposed tile for fp32: a line holds 16 voxels, and the MFMA K order is permuted so that k-group kq of the four k-steps
+// of a row owns voxels 4kq..4kq+3 — ONE ds_read_b128 feeds four v_mfma_f32_16x16x4_f32 k-steps.  The kw = 0 / 2 taps take the
+// same X fragment against dY shifted by one voxel: pure register selection from (left neighbour, fragment, right neighbour) of
+// dY, done once per row.  A 2x6x16-voxel tile costs a wave 3 rows x (3 + 9) = 36 LDS reads for 324 MFMAs (v4 issued one 4-byte
+// LDS read per MFMA, round 1's v6 84 reads); every non-MFMA instruction shows up as idle MFMA time.  Staging
+// transposes 4 voxels x 4 channels per lane by register renaming.  Same accumulators and partial layout as v4.
 constexpr int FTW = 16;   // voxels per line
 
 // 16-byte load through an explicitly GLOBAL pointer (global_load_dwordx4: vmcnt only, never lgkmcnt)
@@ -1196,6 +1331,7 @@ conv_mfma_wgrad6_kernel(const float* __restrict__ x, const float* __restrict__ d
     extern __shared__ __attribute__((aligned(16))) float lds[];
     char* xs = reinterpret_cast<char*>(lds);
     char* ys = xs + BXS;
+    char* yh = ys + BYS;
 
     const int cit = blockIdx.y, cob = blockIdx.z;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -1206,31 +1342,36 @@ conv_mfma_wgrad6_kernel(const float* __restrict__ x, const float* __restrict__ d
     for (int t = 0; t < TGA; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     // staging roles: a unit = 4 consecutive voxels x 4 channels; X has 32 rows x 4 w-groups x 4 quads = 512 units (2 per
-    // lane), its halo 32 rows x 2 sides x 4 quads = 256 (1 per lane), dY 12 rows x 4 x 4 = 192 units (lanes < 192)
+    // lane), dY 12 rows x 4 x 4 = 192 units (lanes < 192), its W halo 12 rows x 2 sides x 4 quads = 96 voxels (lanes < 96)
     const int s_q = tid & 3, s_wg = (tid >> 2) & 3, s_row = tid >> 4;      // unit u = tid (+256): row = s_row (+16)
     const int h_q = tid & 3, h_side = (tid >> 2) & 1, h_row = tid >> 3;
     const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
-    const int p_off = kq == 0 ? 64 : 16 * kq - 4, n_off = kq == 3 ? 68 : 16 * kq + 16, g_off = 16 * kq;
     const int orow0 = wv * (BYR / 4);   // first of the wave's three output rows (same d-plane, consecutive h)
-    const char* const xrow0 = xs + (((orow0 / BTH) * BHH + orow0 % BTH) * 16 + li) * BRS;   // X line of tap (kd,kh) = (0,0)
-    const char* const yrow0 = ys + (orow0 * 16 + li) * BRS + 16 * kq;
+    const char* const xrow0 = xs + (((orow0 / BTH) * BHH + orow0 % BTH) * 16 + li) * DLS + 16 * rot_slot(kq, li);   // tap (kd,kh) = (0,0)
+    const int yline0 = orow0 * 16 + li;
+    const char* const yrow0 = ys + yline0 * DLS + 16 * rot_slot(kq, li);
+    // voxel before / after the lane's four: last float of the previous / first float of the next k-group's slot, or the W halo
+    const char* const ypl0 = kq == 0 ? yh + yline0 * 8 : ys + yline0 * DLS + 16 * rot_slot(kq - 1, li) + 12;
+    const char* const ynr0 = kq == 3 ? yh + yline0 * 8 + 4 : ys + yline0 * DLS + 16 * rot_slot(kq + 1, li);
+    const int pl_step = kq == 0 ? 16 * 8 : 16 * DLS, nr_step = kq == 3 ? 16 * 8 : 16 * DLS;
 
     // next tile's pieces: fetched into registers while the current tile is multiplied (HBM/L2 latency hidden), written to
     // the single LDS tile between two barriers after it
     float4 vx[2][4], vh, vy[4];
     // Per-lane element offsets of its pieces from the tile's origin voxels, computed once: a piece's address is then a
-    // wave-uniform tile base + a 32-bit lane offset (+ j voxels), with no per-tile vector multiplies or 64-bit mads (18
-    // v_mul_lo_u32 + 22 64-bit ops per tile before — quarter-rate work the MFMAs do not hide).  X origin = voxel
-    // (d0-1, h0-1, w0-1), dY origin = (d0, h0, w0); out-of-volume pieces read the tile's first output voxel (always valid).
+    // wave-uniform tile base + a 32-bit lane offset (+ j voxels), with no per-tile vector multiplies or 64-bit mads.
+    // X origin = voxel (d0-1, h0-1, w0), dY origin = (d0, h0, w0); out-of-volume pieces read the tile's first output voxel.
     unsigned xrel[2], yrel;
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
         const int row = s_row + 16 * u;
-        xrel[u] = (unsigned)((((row / BHH) * H + row % BHH) * W + 1 + 4 * s_wg) * x_ld + 4 * s_q);
+        xrel[u] = (unsigned)((((row / BHH) * H + row % BHH) * W + 4 * s_wg) * x_ld + 4 * s_q);
     }
-    const unsigned hrel = (unsigned)((((h_row / BHH) * H + h_row % BHH) * W + (h_side ? FTW + 1 : 0)) * x_ld + 4 * h_q);
-    const unsigned xsafe = (unsigned)(((H + 1) * W + 1) * x_ld);
+    const unsigned xsafe = (unsigned)(((H + 1) * W) * x_ld);
     yrel = (unsigned)((((s_row / BTH) * H + s_row % BTH) * W + 4 * s_wg) * y_ld + 4 * s_q);
+    // halo voxel relative to (d0, h0, w0 - 1): never negative
+    const unsigned hrel = (unsigned)((((h_row / BTH) * H + h_row % BTH) * W + (h_side ? FTW + 1 : 0)) * y_ld + 4 * h_q);
+    const bool co_full = cob * 16 + 16 <= Co;
     auto load_tile = [&](int tile) {
         const int w0 = (tile % tilesW) * FTW;
         tile /= tilesW;
@@ -1239,9 +1380,27 @@ conv_mfma_wgrad6_kernel(const float* __restrict__ x, const float* __restrict__ d
         const int d0 = (tile % tilesD) * BTD;
         const int n = tile / tilesD;
         // wave-uniform bases; the X base may point before the tensor (d0 = 0 ...) and is only dereferenced at valid offsets
-        const float* xb = x + ((((int64_t)n * D + d0 - 1) * H + h0 - 1) * W + w0 - 1) * x_ld + cit * 16;
+        const float* xb = x + ((((int64_t)n * D + d0 - 1) * H + h0 - 1) * W + w0) * x_ld + cit * 16;
         const int c0 = cob * 16 + 4 * s_q;
         const float* yb = dy + ((((int64_t)n * D + d0) * H + h0) * W + w0) * y_ld + cob * 16;
+        // Interior tile (the common case; wave-uniform test on scalars): every piece is in the volume, so a piece's address is
+        // a scalar base (tile origin + j voxels) plus the lane's precomputed 32-bit offset — no per-lane coordinates, no masks.
+        // The general path below costs ~300 instructions per tile against the tile's 336 MFMAs per wave, and none of them hides
+        // behind the fp32 MFMA.
+        if (d0 >= 1 && d0 + BTD < D && h0 >= 1 && h0 + BTH < H && w0 >= 1 && w0 + FTW < W && co_full) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float* xj = xb + j * x_ld;   // scalar
+                vx[0][j] = ldg4(xj + xrel[0]);
+                vx[1][j] = ldg4(xj + xrel[1]);
+            }
+            if (tid < BYR * 16) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) vy[j] = ldg4(yb + j * y_ld + yrel);
+            }
+            if (tid < BYR * 8) vh = ldg4(yb - y_ld + hrel);
+            return;
+        }
 #pragma unroll
         for (int u = 0; u < 2; ++u) {   // ---- X
             const int row = s_row + 16 * u;
@@ -1254,12 +1413,6 @@ conv_mfma_wgrad6_kernel(const float* __restrict__ x, const float* __restrict__ d
                 vx[u][j] = ok ? t : zero4;
             }
         }
-        {   // ---- X halo voxels
-            const int gd = d0 - 1 + h_row / BHH, gh = h0 - 1 + h_row % BHH, gw = h_side ? w0 + FTW : w0 - 1;
-            const bool ok = (unsigned)gd < (unsigned)D && (unsigned)gh < (unsigned)H && (unsigned)gw < (unsigned)W;
-            const float4 t = ldg4(xb + (ok ? hrel : xsafe));
-            vh = ok ? t : zero4;
-        }
         if (tid < BYR * 16) {   // ---- dY
             const int gd = d0 + s_row / BTH, gh = h0 + s_row % BTH;
             const bool rok = gd < D && gh < H && c0 < Co;       // host guarantees Co % 4 == 0
@@ -1270,29 +1423,36 @@ conv_mfma_wgrad6_kernel(const float* __restrict__ x, const float* __restrict__ d
                 vy[j] = ok ? t : zero4;
             }
         }
+        if (tid < BYR * 8) {   // ---- dY W-halo voxels w0 - 1 / w0 + 16
+            const int gd = d0 + h_row / BTH, gh = h0 + h_row % BTH, gw = h_side ? w0 + FTW : w0 - 1;
+            const int hc = cob * 16 + 4 * h_q;
+            const bool ok = gd < D && gh < H && (unsigned)gw < (unsigned)W && hc < Co;
+            const float4 t = ldg4(dy + ((((int64_t)n * D + (ok ? gd : d0)) * H + (ok ? gh : h0)) * W + (ok ? gw : w0)) * y_ld + (ok ? hc : 0));
+            vh = ok ? t : zero4;
+        }
     };
     auto store_tile = [&]() {
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
-            char* dst = xs + ((s_row + 16 * u) * 16 + 4 * s_q) * BRS + 16 * s_wg;
+            char* dst = xs + ((s_row + 16 * u) * 16 + 4 * s_q) * DLS + 16 * rot_slot(s_wg, 4 * s_q);   // 4 channels share a rotation
             *reinterpret_cast<float4*>(dst) = make_float4(vx[u][0].x, vx[u][1].x, vx[u][2].x, vx[u][3].x);
-            *reinterpret_cast<float4*>(dst + BRS) = make_float4(vx[u][0].y, vx[u][1].y, vx[u][2].y, vx[u][3].y);
-            *reinterpret_cast<float4*>(dst + 2 * BRS) = make_float4(vx[u][0].z, vx[u][1].z, vx[u][2].z, vx[u][3].z);
-            *reinterpret_cast<float4*>(dst + 3 * BRS) = make_float4(vx[u][0].w, vx[u][1].w, vx[u][2].w, vx[u][3].w);
-        }
-        {
-            char* dst = xs + (h_row * 16 + 4 * h_q) * BRS + 64 + 4 * h_side;
-            *reinterpret_cast<float*>(dst) = vh.x;
-            *reinterpret_cast<float*>(dst + BRS) = vh.y;
-            *reinterpret_cast<float*>(dst + 2 * BRS) = vh.z;
-            *reinterpret_cast<float*>(dst + 3 * BRS) = vh.w;
+            *reinterpret_cast<float4*>(dst + DLS) = make_float4(vx[u][0].y, vx[u][1].y, vx[u][2].y, vx[u][3].y);
+            *reinterpret_cast<float4*>(dst + 2 * DLS) = make_float4(vx[u][0].z, vx[u][1].z, vx[u][2].z, vx[u][3].z);
+            *reinterpret_cast<float4*>(dst + 3 * DLS) = make_float4(vx[u][0].w, vx[u][1].w, vx[u][2].w, vx[u][3].w);
         }
         if (tid < BYR * 16) {
-            char* dst = ys + (s_row * 16 + 4 * s_q) * BRS + 16 * s_wg;
+            char* dst = ys + (s_row * 16 + 4 * s_q) * DLS + 16 * rot_slot(s_wg, 4 * s_q);
             *reinterpret_cast<float4*>(dst) = make_float4(vy[0].x, vy[1].x, vy[2].x, vy[3].x);
-            *reinterpret_cast<float4*>(dst + BRS) = make_float4(vy[0].y, vy[1].y, vy[2].y, vy[3].y);
-            *reinterpret_cast<float4*>(dst + 2 * BRS) = make_float4(vy[0].z, vy[1].z, vy[2].z, vy[3].z);
-            *reinterpret_cast<float4*>(dst + 3 * BRS) = make_float4(vy[0].w, vy[1].w, vy[2].w, vy[3].w);
+            *reinterpret_cast<float4*>(dst + DLS) = make_float4(vy[0].y, vy[1].y, vy[2].y, vy[3].y);
+            *reinterpret_cast<float4*>(dst + 2 * DLS) = make_float4(vy[0].z, vy[1].z, vy[2].z, vy[3].z);
+            *reinterpret_cast<float4*>(dst + 3 * DLS) = make_float4(vy[0].w, vy[1].w, vy[2].w, vy[3].w);
+        }
+        if (tid < BYR * 8) {
+            char* dst = yh + (h_row * 16 + 4 * h_q) * 8 + 4 * h_side;
+            *reinterpret_cast<float*>(dst) = vh.x;
+            *reinterpret_cast<float*>(dst + 8) = vh.y;
+            *reinterpret_cast<float*>(dst + 16) = vh.z;
+            *reinterpret_cast<float*>(dst + 24) = vh.w;
         }
     };
 
@@ -1310,27 +1470,28 @@ conv_mfma_wgrad6_kernel(const float* __restrict__ x, const float* __restrict__ d
         // immediate offset — no per-row address arithmetic (each VALU instruction costs MFMA time)
         const char* xrow = xrow0;
         const char* yrow = yrow0;
+        const char* ypl = ypl0;
+        const char* ynr = ynr0;
 #pragma unroll 1
-        for (int r = 0; r < BYR / 4; ++r, xrow += 16 * BRS, yrow += 16 * BRS) {
+        for (int r = 0; r < BYR / 4; ++r, xrow += 16 * DLS, yrow += 16 * DLS, ypl += pl_step, ynr += nr_step) {
             const float4 b = *reinterpret_cast<const float4*>(yrow);
-            const float bk[4] = {b.x, b.y, b.z, b.w};
+            const float pl = *reinterpret_cast<const float*>(ypl);   // dY[first - 1]
+            const float nr = *reinterpret_cast<const float*>(ynr);   // dY[last + 1]
+            const float b0[4] = {b.y, b.z, b.w, nr}, b1[4] = {b.x, b.y, b.z, b.w}, b2[4] = {pl, b.x, b.y, b.z};   // dY[u+1], dY[u], dY[u-1]
             if (BIAS) {
 #pragma unroll
-                for (int j = 0; j < 4; ++j) acc[TG] = __builtin_amdgcn_mfma_f32_16x16x4f32(1.0f, bk[j], acc[TG], 0, 0, 0);
+                for (int j = 0; j < 4; ++j) acc[TG] = __builtin_amdgcn_mfma_f32_16x16x4f32(1.0f, b1[j], acc[TG], 0, 0, 0);
             }
 #pragma unroll
             for (int kdh = 0; kdh < 9; ++kdh) {
-                constexpr int kOff = 0;
-                const int loff = ((kdh / 3) * BHH + kdh % 3) * 16 * BRS + kOff;   // compile-time after unrolling
-                const float4 g = *reinterpret_cast<const float4*>(xrow + g_off + loff);
-                const float pp = *reinterpret_cast<const float*>(xrow + p_off + loff);
-                const float nn = *reinterpret_cast<const float*>(xrow + n_off + loff);
-                const float a0[4] = {pp, g.x, g.y, g.z}, a1[4] = {g.x, g.y, g.z, g.w}, a2[4] = {g.y, g.z, g.w, nn};
+                const int lrow = ((kdh / 3) * BHH + kdh % 3) * 16;   // compile-time after unrolling
+                const float4 g = *reinterpret_cast<const float4*>(xrow + lrow * DLS);
+                const float a[4] = {g.x, g.y, g.z, g.w};
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    acc[kdh * 3 + 0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[j], bk[j], acc[kdh * 3 + 0], 0, 0, 0);
-                    acc[kdh * 3 + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[j], bk[j], acc[kdh * 3 + 1], 0, 0, 0);
-                    acc[kdh * 3 + 2] = __builtin_amdgcn_mfma_f32_16x16x4f32(a2[j], bk[j], acc[kdh * 3 + 2], 0, 0, 0);
+                    acc[kdh * 3 + 0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j], b0[j], acc[kdh * 3 + 0], 0, 0, 0);
+                    acc[kdh * 3 + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j], b1[j], acc[kdh * 3 + 1], 0, 0, 0);
+                    acc[kdh * 3 + 2] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j], b2[j], acc[kdh * 3 + 2], 0, 0, 0);
                 }
             }
         }
@@ -1454,7 +1615,7 @@ static bool mfma_wgrad_plan(const Mri3dConvGeom& g, MfmaWgradPlan& p) {
     } else if (p.v2 == 2) {
         p.smem = std::max<size_t>((size_t)2 * V4XBUF + 2 * V4YBUF, red) * sizeof(float);
     } else if (p.v2 >= 3) {
-        p.smem = std::max<size_t>((size_t)BXS + BYS, red * sizeof(float));
+        p.smem = std::max<size_t>((size_t)BXS + BYS + BYH, red * sizeof(float));
     }
     return true;
 }

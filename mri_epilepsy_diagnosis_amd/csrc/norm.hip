@@ -145,7 +145,8 @@ __global__ void __launch_bounds__(256)
 norm_stats_finalize_kernel(const T* __restrict__ x, const double* __restrict__ part,
                            float* __restrict__ mean, float* __restrict__ invstd,
                            float* __restrict__ running_mean, float* __restrict__ running_var,
-                           float momentum, float eps, int C, int ld, int64_t gvox, int nblk, int groups) {
+                           float momentum, float eps, int C, int ld, int64_t gvox, int nblk, int groups,
+                           const float* __restrict__ shift = nullptr, int use_shift = 0) {
     // 256 threads = 4 (group,channel) slots x kFinQL partial lanes
     __shared__ double ra[256], rb[256];
     const int slot = threadIdx.x / kFinQL, ql = threadIdx.x % kFinQL;
@@ -180,7 +181,9 @@ norm_stats_finalize_kernel(const T* __restrict__ x, const double* __restrict__ p
         a += ra[slot * kFinQL + q];
         b += rb[slot * kFinQL + q];
     }
-    double k = (double)x[(int64_t)group * gvox * ld + c];
+    // the partial sums are of (x - k): k = the first voxel's value (norm_stats_kernel), or the caller's per-channel shift (the
+    // conv epilogue's sums are of the result without its bias: k = bias, or 0 without one)
+    double k = use_shift ? (shift != nullptr ? (double)shift[c] : 0.0) : (double)x[(int64_t)group * gvox * ld + c];
     double cnt = (double)gvox;
     double dm = a / cnt;
     double var = b / cnt - dm * dm;
@@ -570,6 +573,22 @@ extern "C" int mri3d_norm_stats(const Mri3dNormGeom* g, const void* x, float* me
         }
     });
     return check_launch("norm_stats");
+}
+
+extern "C" int mri3d_norm_stats_from_partials(const Mri3dNormGeom* g, const double* partials, int32_t nblk, const float* shift,
+                                              float* mean, float* invstd, float* running_mean, float* running_var,
+                                              float momentum, mri3d_stream_t stream) {
+    int rc = norm_check(g, "norm_stats_from_partials");
+    if (rc) return rc;
+    MRI3D_REQUIRE(partials && mean && invstd && nblk > 0, MRI3D_EINVAL, "norm_stats_from_partials: null pointer / no partials");
+    MRI3D_REQUIRE(!g->instance && g->group_c == 0, MRI3D_ENOTSUP,
+                  "norm_stats_from_partials: batch statistics only (one group over N x voxels)");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int64_t gvox = (int64_t)g->n * g->vox;
+    hipLaunchKernelGGL(norm_stats_finalize_kernel<float>, dim3(cdiv(g->c, 256 / kFinQL)), dim3(256), 0, s,
+                       static_cast<const float*>(nullptr), partials, mean, invstd, running_mean, running_var, momentum, g->eps,
+                       g->c, g->x_ld, gvox, nblk, 1, shift, 1);
+    return check_launch("norm_stats_from_partials");
 }
 
 extern "C" int mri3d_norm_act_fwd(const Mri3dNormGeom* g, const void* x, const float* mean, const float* invstd,

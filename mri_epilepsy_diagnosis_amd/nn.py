@@ -70,6 +70,20 @@ def fused_norm_act(norm, act, x, out=None):
     raise NotImplementedError("unsupported normalisation module %r" % (norm,))
 
 
+def conv_norm_act(conv, norm, act, x, out=None):
+    """act(norm(conv(x))) for a Conv3d module followed by a normalisation (`unet.UNet`'s ConvolutionalBlock, the conv -> BN ->
+    ReLU stems of cnn_model.py).  When `norm` is a BatchNorm3d that will use BATCH statistics (training mode, local statistics)
+    the convolution is asked to accumulate them in its epilogue, which saves the statistics pass over its output."""
+    wants = (isinstance(norm, tnn.modules.batchnorm._BatchNorm) and (norm.training or norm.running_mean is None)
+             and ops.sync_batchnorm_reducer() is None and isinstance(conv, Conv3d) and conv.padding_mode == "zeros"
+             and conv.groups == 1 and not isinstance(conv.padding, str))
+    if wants:
+        y = ops.conv3d(x, conv.weight, conv.bias, conv.stride, conv.padding, conv.dilation, bn_stats=True)
+    else:
+        y = conv(x)
+    return fused_norm_act(norm, act, y, out)
+
+
 class GroupNorm(tnn.GroupNorm):
     def forward(self, x):
         return fused_norm_act(self, None, x)
@@ -147,6 +161,15 @@ def run_fused(modules, x):
     while i < len(mods):
         m = mods[i]
         five_d = torch.is_tensor(x) and x.dim() == 5
+        if five_d and isinstance(m, Conv3d) and i + 1 < len(mods) and isinstance(mods[i + 1], tnn.BatchNorm3d):
+            nxt2 = mods[i + 2] if i + 2 < len(mods) else None
+            if isinstance(nxt2, _ACTS):
+                x = conv_norm_act(m, mods[i + 1], nxt2, x)
+                i += 3
+            else:
+                x = conv_norm_act(m, mods[i + 1], None, x)
+                i += 2
+            continue
         if five_d and isinstance(m, (tnn.BatchNorm3d, tnn.InstanceNorm3d, tnn.GroupNorm)):
             nxt = mods[i + 1] if i + 1 < len(mods) else None
             if isinstance(nxt, _ACTS):

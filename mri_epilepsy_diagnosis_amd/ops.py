@@ -393,13 +393,28 @@ def _conv_wgrad(g, x, dy, w_like, want_bias, dw_out=None, db_out=None):
 
 class _Conv3dFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, weight, bias, stride, padding, dilation):
+    def forward(ctx, x, weight, bias, stride, padding, dilation, stats_holder=None):
         _require_device(x)
         _require_param(weight, bias)
         x, x_ld = _nd(x)
         w = weight.contiguous()
         g = _conv_geom(x.shape, w.shape, stride, padding, dilation, x_ld=x_ld, dtype=_dt(x))
-        y = _conv_fwd(g, x, w, bias)
+        y = None
+        if stats_holder is not None:
+            # BatchNorm follows in batch-statistics mode: let the conv epilogue accumulate sum(a), sum(a^2) per output channel
+            # (float64 partials, one per workgroup) instead of a statistics pass over y afterwards
+            L = _lib.lib()
+            blocks = L.mri3d_conv3d_fwd_stats_blocks(ctypes.byref(g))
+            if blocks > 0:
+                y = _new((g.n, g.co, g.dout, g.ho, g.wo), x)
+                part = torch.empty(blocks * g.co * 2, dtype=torch.float64, device=x.device)
+                ws = _workspace(L.mri3d_conv3d_workspace_bytes(ctypes.byref(g), PASS_FWD), x.device)
+                with _timed(lambda: _conv_tag("fwd", g) + " +bn-stats", lambda: _conv_work(g, "fwd")):
+                    check(L.mri3d_conv3d_fwd_stats(ctypes.byref(g), _ptr(x), _ptr(w), _ptr(bias), _ptr(y), _ptr(part), _ptr(ws),
+                                                   ws.numel(), _stream()), "conv3d_fwd_stats")
+                stats_holder.append((part, blocks, bias.detach() if bias is not None else None))
+        if y is None:
+            y = _conv_fwd(g, x, w, bias)
         ctx.save_for_backward(x, w)
         ctx.geom = g
         ctx.has_bias = bias is not None
@@ -426,13 +441,19 @@ class _Conv3dFn(torch.autograd.Function):
             dw, db = _conv_wgrad(gw, x, dy, w, ctx.has_bias, dw_out, db_out)
             dw = _sink_done(wp, dw, dw_out) if ctx.needs_input_grad[1] else None
             db = _sink_done(bp, db, db_out) if want_b else None
-        return dx, dw, db, None, None, None
+        return dx, dw, db, None, None, None, None
 
 
-def conv3d(x, weight, bias=None, stride=1, padding=0, dilation=1):
+def conv3d(x, weight, bias=None, stride=1, padding=0, dilation=1, bn_stats=False):
+    """bn_stats=True: the caller applies a batch-statistics BatchNorm to the result next (nn.conv_norm_act); where the MFMA
+    forward kernel serves the geometry its epilogue accumulates the statistics, and `norm_act` picks them up from the result."""
     if _autocast_dtype is not None and x.dtype != _autocast_dtype:
         x = convert(x, _autocast_dtype)
-    return _Conv3dFn.apply(x, weight, bias, _triple(stride), _triple(padding), _triple(dilation))
+    holder = [] if bn_stats else None
+    y = _Conv3dFn.apply(x, weight, bias, _triple(stride), _triple(padding), _triple(dilation), holder)
+    if holder:
+        y._mri3d_bn_stats = holder[0]
+    return y
 
 
 def _channel_sum(t):
@@ -523,7 +544,8 @@ class _NormActFn(torch.autograd.Function):
     """y = act(gamma * (x - mean) / sqrt(var + eps) + beta) with batch, instance, running or no statistics."""
 
     @staticmethod
-    def forward(ctx, x, gamma, beta, alpha, running_mean, running_var, stats_mode, momentum, eps, act, slope, out, group_c=0):
+    def forward(ctx, x, gamma, beta, alpha, running_mean, running_var, stats_mode, momentum, eps, act, slope, out, group_c=0,
+                fused_stats=None):
         # stats_mode: "batch" (compute + update running), "instance", "running" (eval BN), "none" (activation only)
         # out: None, or (buffer, channel_offset): write y into that channel slice of a wider NDHWC buffer
         _require_device(x)
@@ -554,12 +576,21 @@ class _NormActFn(torch.autograd.Function):
             groups = n if instance else 1
             mean = torch.empty(groups * c, dtype=torch.float32, device=x.device)
             invstd = torch.empty(groups * c, dtype=torch.float32, device=x.device)
-            ws = _workspace(L.mri3d_norm_workspace_bytes(ctypes.byref(g)), x.device)
             upd = stats_mode == "batch" and running_mean is not None
-            with _timed(lambda: "norm_stats c%d vox%d n%d" % (c, g.vox, n), lambda: {"flops": 0.0, "bytes": _esz(x) * x.numel()}):
-                check(L.mri3d_norm_stats(ctypes.byref(g), _ptr(x), _ptr(mean), _ptr(invstd),
-                                         _ptr(running_mean) if upd else None, _ptr(running_var) if upd else None,
-                                         float(momentum), _ptr(ws), ws.numel(), _stream()), "norm_stats")
+            if fused_stats is not None and fused_stats[0].numel() == fused_stats[1] * c * 2:
+                # the producing conv's epilogue already summed (y - bias), (y - bias)^2 per channel: only the finalize kernel runs
+                part, blocks, shift = fused_stats
+                with _timed(lambda: "norm_stats(from conv partials) c%d" % c, lambda: {"flops": 0.0, "bytes": 8.0 * part.numel()}):
+                    check(L.mri3d_norm_stats_from_partials(ctypes.byref(g), _ptr(part), blocks, _ptr(shift), _ptr(mean),
+                                                           _ptr(invstd), _ptr(running_mean) if upd else None,
+                                                           _ptr(running_var) if upd else None, float(momentum), _stream()),
+                          "norm_stats_from_partials")
+            else:
+                ws = _workspace(L.mri3d_norm_workspace_bytes(ctypes.byref(g)), x.device)
+                with _timed(lambda: "norm_stats c%d vox%d n%d" % (c, g.vox, n), lambda: {"flops": 0.0, "bytes": _esz(x) * x.numel()}):
+                    check(L.mri3d_norm_stats(ctypes.byref(g), _ptr(x), _ptr(mean), _ptr(invstd),
+                                             _ptr(running_mean) if upd else None, _ptr(running_var) if upd else None,
+                                             float(momentum), _ptr(ws), ws.numel(), _stream()), "norm_stats")
         elif stats_mode == "sync":
             # local moments with the statistics kernel, summed over the ranks as (count, sum x, sum x^2) in float64
             reducer = _sync_bn_reducer
@@ -656,15 +687,16 @@ class _NormActFn(torch.autograd.Function):
             check(L.mri3d_add_channels(_ptr(dx), _ptr(corr), _ptr(dx), g.n * g.vox, g.c, g.c, g.c, g.c, g.dtype, _stream()),
                   "add_channels")
         return (dx, _sink_done(pg, dgamma, sg), _sink_done(pb, dbeta, sb), _sink_done(pa, dalpha, sa), None, None, None, None,
-                None, None, None, None, None)
+                None, None, None, None, None, None)
 
 
 def norm_act(x, gamma=None, beta=None, alpha=None, running_mean=None, running_var=None, stats_mode="batch",
              momentum=0.1, eps=1e-5, act=None, slope=0.01, out=None, group_c=0):
     if momentum is None:
         raise RuntimeError("cumulative moving average (momentum=None) is not supported")
+    fused = getattr(x, "_mri3d_bn_stats", None) if stats_mode == "batch" else None
     return _NormActFn.apply(x, gamma, beta, alpha, running_mean, running_var, stats_mode, momentum, eps, act, slope, out,
-                            group_c)
+                            group_c, fused)
 
 
 def activation(x, act, alpha=None, slope=0.01):

@@ -45,7 +45,7 @@ class ConvolutionalBlock(tnn.Module):
         self.block = tnn.Sequential(*[m for m in (conv, norm, act) if m is not None])
 
     def forward(self, x, out=None):
-        return mnn.fused_norm_act(self.norm_layer, self.activation_layer, self.conv_layer(x), out)
+        return mnn.conv_norm_act(self.conv_layer, self.norm_layer, self.activation_layer, x, out)
 
 
 class EncodingBlock(tnn.Module):

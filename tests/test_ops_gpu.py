@@ -485,3 +485,40 @@ def test_surface_element_lists_and_order_metrics_bit_exact():
     assert surface.compute_robust_hausdorff(sd, 95) == np.inf
     sd = surface.surface_distances(torch.from_numpy(z).cuda(), torch.from_numpy(z).cuda())
     assert all(len(v) == 0 for v in sd.values())
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
+@pytest.mark.parametrize("case", [(2, 16, 16, 9, 13, 21, True), (1, 48, 16, 8, 16, 32, True), (2, 8, 32, 5, 8, 16, False),
+                                  (1, 32, 64, 4, 9, 17, True), (1, 16, 48, 6, 7, 19, True)],
+                         ids=lambda c: "n%d_%d-%d_%dx%dx%d_b%d" % c)
+def test_batchnorm_statistics_from_the_conv_epilogue_equal_the_statistics_pass(case, dtype):
+    """conv3d(bn_stats=True) accumulates the BatchNorm batch statistics in the MFMA kernel's epilogue (float64 partials per
+    workgroup, shift = bias); norm_act must then give what it gives with its own statistics pass over y: outputs, running
+    statistics, and all gradients — on ragged sizes (masked tile borders), one and two N-tiles per wave, several passes (Cout 48)."""
+    nb, ci, co, d, h, w, has_bias = case
+    g = torch.Generator().manual_seed(7)
+    x = (torch.randn(nb, ci, d, h, w, generator=g) * 1.5 + 0.3).cuda().to(dtype).contiguous(memory_format=torch.channels_last_3d)
+    wt = (torch.randn(co, ci, 3, 3, 3, generator=g) / np.sqrt(27 * ci)).cuda()
+    b = (torch.randn(co, generator=g) * 2.0).cuda() if has_bias else None
+    gamma, beta = (torch.rand(co, generator=g) + 0.5).cuda(), torch.randn(co, generator=g).cuda()
+    dy = torch.randn(nb, co, d, h, w, generator=g).cuda().to(dtype).contiguous(memory_format=torch.channels_last_3d)
+    res = []
+    for fused in (False, True):
+        xs = x.clone().requires_grad_(True)
+        ws, bs = wt.clone().requires_grad_(True), (b.clone().requires_grad_(True) if has_bias else None)
+        gs, be = gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+        rm, rv = torch.zeros(co, device="cuda"), torch.ones(co, device="cuda")
+        y = ops.conv3d(xs, ws, bs, padding=1, bn_stats=fused)
+        assert hasattr(y, "_mri3d_bn_stats") == fused
+        z = ops.norm_act(y, gs, be, None, rm, rv, "batch", 0.1, 1e-5, "relu")
+        z.backward(dy)
+        res.append([z.detach().float(), rm, rv, xs.grad.float(), ws.grad, gs.grad, be.grad] + ([bs.grad] if has_bias else []))
+    tol = 2e-5 if dtype == torch.float32 else 2e-2     # bf16: the fused statistics see y before its rounding to bf16
+    for a, r in zip(res[1], res[0]):
+        assert (a - r).abs().max().item() <= tol * (r.abs().max().item() + 1e-6), ((a - r).abs().max().item(), r.abs().max().item())
+    # against torch's own batch statistics (fp32 only: exact semantics check incl. the unbiased running variance)
+    if dtype == torch.float32:
+        yr = F.conv3d(x.float().cpu(), wt.cpu(), b.cpu() if has_bias else None, padding=1)
+        m, v = yr.mean(dim=(0, 2, 3, 4)), yr.var(dim=(0, 2, 3, 4), unbiased=True)
+        assert torch.allclose(res[1][1].cpu(), 0.1 * m, rtol=1e-4, atol=1e-5)
+        assert torch.allclose(res[1][2].cpu(), 0.9 + 0.1 * v, rtol=1e-4, atol=1e-5)
