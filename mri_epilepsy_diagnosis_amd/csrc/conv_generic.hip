@@ -1017,12 +1017,91 @@ int conv_generic_fwd(const Mri3dConvGeom& g, const void* x, const float* w, cons
     return check_launch("conv3d_fwd(generic)");
 }
 
+// Data gradient of a STRIDED convolution (dilation 1): only the taps with k = (i + pad) mod stride reach an input voxel i, i.e.
+// 1 .. 8 of the 27 taps of a 3x3x3 / stride-2 layer (modified_3dunet.py:23-38, cnn_model.py:49-81).  The gather kernel above
+// walks all taps and masks (8x wasted FMAs: 6 TFLOP/s on the 8 -> 16 stride-2 layer at 80x96x80).  Here one WAVE owns one
+// (n, id, ih, w-parity) row segment: the valid tap set is wave-uniform, so the tap loops just step by the stride, the weights
+// stay on the scalar path and nothing is masked except the volume border.
+template <typename T, int CIT, bool VEC4>
+__global__ void __launch_bounds__(64)
+conv_dgrad_strided_kernel(Mri3dConvGeom g, const T* __restrict__ dy, const float* __restrict__ wp,
+                          const float* __restrict__ bias, T* __restrict__ dx, int CiP) {
+    int u = blockIdx.x;
+    const int rw = u % g.sw;   // residue of iw modulo the W stride handled by this wave
+    u /= g.sw;
+    const int ih = u % g.hi;
+    u /= g.hi;
+    const int id = u % g.di;
+    const int n = u / g.di;
+    const int cit = blockIdx.y * CIT;
+    const int kd0 = (id + g.pd) % g.sd, kh0 = (ih + g.ph) % g.sh, kw0 = (rw + g.pw) % g.sw;
+    for (int iw = rw + (int)threadIdx.x * g.sw; iw < g.wi; iw += 64 * g.sw) {
+        float acc[CIT];
+#pragma unroll
+        for (int j = 0; j < CIT; ++j) acc[j] = (bias != nullptr && cit + j < g.ci) ? bias[cit + j] : 0.f;
+        for (int kd = kd0; kd < g.kd; kd += g.sd) {
+            const int nd = id + g.pd - kd;
+            if (nd < 0) break;
+            const int od = nd / g.sd;
+            if (od >= g.dout) continue;
+            for (int kh = kh0; kh < g.kh; kh += g.sh) {
+                const int nh = ih + g.ph - kh;
+                if (nh < 0) break;
+                const int oh = nh / g.sh;
+                if (oh >= g.ho) continue;
+                for (int kw = kw0; kw < g.kw; kw += g.sw) {
+                    const int nw = iw + g.pw - kw;
+                    const int ow = nw / g.sw;
+                    const bool valid = nw >= 0 && ow < g.wo;
+                    const T* yp = dy + ((((int64_t)n * g.dout + od) * g.ho + oh) * g.wo + (valid ? ow : 0)) * g.y_ld;
+                    const float* wt = wp + (size_t)((kd * g.kh + kh) * g.kw + kw) * g.co * CiP + cit;
+                    if (VEC4) {
+                        for (int co = 0; co < g.co; co += 4) {
+                            const float4 gv = valid ? ldf4(yp + co) : make_float4(0.f, 0.f, 0.f, 0.f);
+                            const float* w0 = wt + (size_t)co * CiP;
+#pragma unroll
+                            for (int j = 0; j < CIT; ++j) {
+                                acc[j] = fmaf(gv.x, w0[j], acc[j]);
+                                acc[j] = fmaf(gv.y, w0[CiP + j], acc[j]);
+                                acc[j] = fmaf(gv.z, w0[2 * CiP + j], acc[j]);
+                                acc[j] = fmaf(gv.w, w0[3 * CiP + j], acc[j]);
+                            }
+                        }
+                    } else {
+                        for (int co = 0; co < g.co; ++co) {
+                            const float gv = valid ? ldf(yp + co) : 0.f;
+                            const float* w0 = wt + (size_t)co * CiP;
+#pragma unroll
+                            for (int j = 0; j < CIT; ++j) acc[j] = fmaf(gv, w0[j], acc[j]);
+                        }
+                    }
+                }
+            }
+        }
+        T* xp = dx + ((((int64_t)n * g.di + id) * g.hi + ih) * g.wi + iw) * g.x_ld + cit;
+#pragma unroll
+        for (int j = 0; j < CIT; ++j)
+            if (cit + j < g.ci) stf(xp + j, acc[j]);
+    }
+}
+
 template <int TL>
 static void launch_dgrad(const Mri3dConvGeom& g, const void* dy, const float* wp, const float* bias, void* dx,
                          int CiP, hipStream_t s) {
     int64_t nvox = (int64_t)g.n * g.di * g.hi * g.wi;
     dim3 grid((unsigned)std::min<int64_t>(cdiv64(nvox, 256), 8192), CiP / TL);
     bool vec = (g.co % 4 == 0) && (g.y_ld % 4 == 0) && aligned_vec4(g.dtype, dy);
+    const int64_t rows = (int64_t)g.n * g.di * g.hi * g.sw;
+    if ((g.sd > 1 || g.sh > 1 || g.sw > 1) && g.dd == 1 && g.dh == 1 && g.dw == 1 && rows <= 0x7fffffff) {
+        dim3 sgrid((unsigned)rows, CiP / TL);
+        MRI3D_DISPATCH_DTYPE(g.dtype, T, {
+            if (vec)
+                hipLaunchKernelGGL((conv_dgrad_strided_kernel<T, TL, true>), sgrid, dim3(64), 0, s, g, (const T*)dy, wp, bias, (T*)dx, CiP);
+            else
+                hipLaunchKernelGGL((conv_dgrad_strided_kernel<T, TL, false>), sgrid, dim3(64), 0, s, g, (const T*)dy, wp, bias, (T*)dx, CiP);
+        });
+        return;
+    }
     MRI3D_DISPATCH_DTYPE(g.dtype, T, {
         if (vec)
             hipLaunchKernelGGL((conv_dgrad_generic_kernel<T, TL, true>), grid, dim3(256), 0, s, g, (const T*)dy, wp, bias, (T*)dx, CiP);

@@ -468,10 +468,98 @@ conv_mfma_fwd2_kernel(const T* __restrict__ x, const float* __restrict__ wp, con
     }
 }
 
+// ------------------------------------------------------------------ forward / dgrad for SMALL volumes (fp32)
+// The tiled kernel above needs thousands of 4x8x16 tiles to fill 512 workgroup slots; the deep levels of Modified3DUNet
+// (modified_3dunet.py:33-70: 64 -> 64 at 20x24x20, 128 -> 128 at 10x12x10, batch 1) have 6 .. 60 of them and ran at 5 .. 10 TFLOP/s,
+// with half-empty tiles on top (W = 10 or 20 against a tile width of 16).  Here a WAVE is the unit: 16 consecutive voxels of the
+// flattened (n, d, h, w) index space x NT N-tiles, the whole K = 27 taps x Cin in one go, operands straight from global memory
+// (the whole input of such a layer is < 1 MB: L2-resident) — no LDS, no barriers, no tile waste.  A lane's voxel coordinates
+// are computed once; a tap is a constant element offset plus three range checks.  Same operand order, K permutation and
+// epilogue as the tiled kernel; packed weights Wp[chunk16][tap][nt][lane][s] (pack_w_mfma_kernel, CK = 16).
+template <int NT>
+__global__ void __launch_bounds__(256)
+conv_mfma_small_kernel(const float* __restrict__ x, const float* __restrict__ wp, const float* __restrict__ bias,
+                       float* __restrict__ y, int N, int D, int H, int W, int Kc, int x_ld, int Nc, int y_ld, int NTT, int gy,
+                       int nmt) {
+    const int lane = threadIdx.x & 63, li = lane & 15, kq = lane >> 4;
+    const int unit = blockIdx.x * 4 + (threadIdx.x >> 6);          // (M-tile, N-block), N-block fastest: the waves of a
+    if (unit >= nmt * gy) return;                                  // workgroup share their voxel fragments through L1
+    const int ntb = unit % gy, mt = unit / gy;
+    const int64_t nvox = (int64_t)N * D * H * W;
+    const int64_t v = (int64_t)mt * 16 + li;
+    const bool vok = v < nvox;
+    const int64_t vc = vok ? v : nvox - 1;
+    const int w0 = (int)(vc % W);
+    int64_t t = vc / W;
+    const int h0 = (int)(t % H);
+    t /= H;
+    const int d0 = (int)(t % D);
+    const float* xv = x + vc * x_ld + 4 * kq;                      // this lane's voxel, its k-group's first channel
+    const int nchunks = (Kc + 15) / 16;
+    const int nt0 = ntb * NT;
+
+    f32x4 acc[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) acc[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const float* wbase = wp + (size_t)nt0 * 256 + lane * 4;
+    const size_t wtap = (size_t)NTT * 256, wchunk = (size_t)27 * NTT * 256;
+
+#pragma unroll 1
+    for (int kd = 0; kd < 3; ++kd) {
+        const bool okd = vok && (unsigned)(d0 + kd - 1) < (unsigned)D;
+#pragma unroll 1
+        for (int kh = 0; kh < 3; ++kh) {
+            const bool okh = okd && (unsigned)(h0 + kh - 1) < (unsigned)H;
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw) {
+                const bool ok = okh && (unsigned)(w0 + kw - 1) < (unsigned)W;
+                const int tap = (kd * 3 + kh) * 3 + kw;
+                const int64_t eoff = ((int64_t)((kd - 1) * H + (kh - 1)) * W + (kw - 1)) * x_ld;
+                const float* src = ok ? xv + eoff : xv;            // clamped address, zeroed below
+                const float* wt = wbase + (size_t)tap * wtap;
+                for (int ch = 0; ch < nchunks; ++ch) {
+                    const bool cok = ok && ch * 16 + 4 * kq < Kc;   // Kc % 4 == 0 (host)
+                    float4 a = *reinterpret_cast<const float4*>(cok ? src + ch * 16 : xv);
+                    if (!cok) a = make_float4(0.f, 0.f, 0.f, 0.f);
+                    const float av[4] = {a.x, a.y, a.z, a.w};
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) {
+                        const f32x4 b = *reinterpret_cast<const f32x4*>(wt + (size_t)ch * wchunk + nt * 256);
+#pragma unroll
+                        for (int s4 = 0; s4 < 4; ++s4)
+                            acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(b[s4], av[s4], acc[nt], 0, 0, 0);
+                    }
+                }
+            }
+        }
+    }
+    if (!vok) return;
+    float* yv = y + v * y_ld;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        const int co = (nt0 + nt) * 16 + 4 * kq;
+        if (co >= Nc) continue;
+        float bv[4] = {0.f, 0.f, 0.f, 0.f};
+        if (bias) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (co + r < Nc) bv[r] = bias[co + r];
+        }
+        if (co + 3 < Nc && (y_ld & 3) == 0) {
+            stf4(yv + co, make_float4(acc[nt][0] + bv[0], acc[nt][1] + bv[1], acc[nt][2] + bv[2], acc[nt][3] + bv[3]));
+        } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (co + r < Nc) yv[co + r] = acc[nt][r] + bv[r];
+        }
+    }
+}
+
 // ------------------------------------------------------------------ host side
 struct MfmaFwdPlan {
     int CK, NT, NTT, gy, nchunks, tilesD, tilesH, tilesW, ntiles, grid;
-    size_t wp_floats, smem, stat_smem;
+    int small, s_nt, s_gy, s_nmt;   // small-volume kernel (fp32): N-tiles per wave, N-blocks, 16-voxel M-tiles
+    size_t wp_floats, s_wp_floats, smem, stat_smem;   // packed-weight image of the tiled / the small-volume kernel
 };
 
 static bool mfma_fwd_plan(const Mri3dConvGeom& g, bool dgrad, MfmaFwdPlan& p) {
@@ -502,6 +590,20 @@ static bool mfma_fwd_plan(const Mri3dConvGeom& g, bool dgrad, MfmaFwdPlan& p) {
     int64_t st = (int64_t)p.ntiles * p.gy;  // (spatial tile, n-tile block) work units
     if (st > 0x7fffffff) return false;
     p.grid = (int)std::min<int64_t>(st, 512);  // 2 resident workgroups per CU x 256 CUs
+    // Small volumes (fp32): fewer work units than workgroup slots — the wave-per-M-tile kernel fills the chip instead.  Its
+    // operands come from L2 / the Infinity Cache, so it is only used while the input is small (<= 32 MB) and the tiled grid would be under half full.
+    p.small = 0;
+    p.s_wp_floats = 0;
+    const int64_t nvox = (int64_t)g.n * g.di * g.hi * g.wi;
+    if (!bf && st < 256 && nvox * Kc * 4 <= ((int64_t)32 << 20) && nvox < 0x7fffffff) {
+        p.small = 1;
+        p.s_nt = (p.NTT % 4 == 0) ? 4 : ((p.NTT % 2 == 0) ? 2 : 1);
+        p.s_nmt = (int)((nvox + 15) / 16);
+        // enough waves for ~4 per SIMD where the layer allows it: narrower N-blocks when there are few M-tiles
+        while (p.s_nt > 1 && (int64_t)p.s_nmt * (p.NTT / p.s_nt) < 4096) p.s_nt >>= 1;
+        p.s_gy = p.NTT / p.s_nt;
+        p.s_wp_floats = (size_t)cdiv(Kc, 16) * 27 * p.NTT * 256;   // [chunk16][tap][nt][lane][s]
+    }
     return true;
 }
 
@@ -509,14 +611,29 @@ static int run_mfma_fwd(const Mri3dConvGeom& g, bool dgrad, const void* in_v, co
                         void* out_v, void* ws, size_t ws_bytes, hipStream_t s, double* stat_part = nullptr) {
     MfmaFwdPlan p;
     MRI3D_REQUIRE(mfma_fwd_plan(g, dgrad, p), MRI3D_ENOTSUP, "conv3d(mfma): unsupported geometry");
-    MRI3D_REQUIRE(ws && ws_bytes >= p.wp_floats * sizeof(float), MRI3D_EWORKSPACE, "conv3d(mfma): workspace %zu < %zu",
-                  ws_bytes, p.wp_floats * sizeof(float));
+    const size_t need = std::max(p.wp_floats, p.s_wp_floats) * sizeof(float);
+    MRI3D_REQUIRE(ws && ws_bytes >= need, MRI3D_EWORKSPACE, "conv3d(mfma): workspace %zu < %zu", ws_bytes, need);
     MRI3D_REQUIRE(((reinterpret_cast<uintptr_t>(in_v) | reinterpret_cast<uintptr_t>(out_v) | reinterpret_cast<uintptr_t>(ws)) & 15) == 0,
                   MRI3D_EINVAL, "conv3d(mfma): input/output/workspace must be 16-byte aligned");
     float* wp = static_cast<float*>(ws);
     const int Kc = dgrad ? g.co : g.ci, Nc = dgrad ? g.ci : g.co;
     const int in_ld = dgrad ? g.y_ld : g.x_ld, out_ld = dgrad ? g.x_ld : g.y_ld;
     int total = (int)p.wp_floats;
+    if (p.small && stat_part == nullptr) {
+        const int stotal = (int)p.s_wp_floats;
+        hipLaunchKernelGGL(pack_w_mfma_kernel, dim3(std::min(cdiv(stotal, 256), 2048)), dim3(256), 0, s, w, wp, g.co, g.ci,
+                           dgrad ? 1 : 0, 16, p.NTT, cdiv(Kc, 16));
+        const int units = p.s_nmt * p.s_gy;
+#define MRI3D_SMALL_CASE(NTv)                                                                                         \
+    if (p.s_nt == NTv)                                                                                                \
+        hipLaunchKernelGGL(conv_mfma_small_kernel<NTv>, dim3(cdiv(units, 4)), dim3(256), 0, s, (const float*)in_v, wp, \
+                           bias, (float*)out_v, g.n, g.di, g.hi, g.wi, Kc, in_ld, Nc, out_ld, p.NTT, p.s_gy, p.s_nmt);
+        MRI3D_SMALL_CASE(1)
+        MRI3D_SMALL_CASE(2)
+        MRI3D_SMALL_CASE(4)
+#undef MRI3D_SMALL_CASE
+        return check_launch(dgrad ? "conv3d_dgrad(mfma small)" : "conv3d_fwd(mfma small)");
+    }
     if (g.dtype == MRI3D_BF16)   // same image size in bytes: 256 floats == 512 bf16 per (chunk, tg, nt)
         hipLaunchKernelGGL(pack_w_mfma_bf16_kernel, dim3(std::min(cdiv(2 * total, 256), 2048)), dim3(256), 0, s, w,
                            reinterpret_cast<bf16_t*>(wp), g.co, g.ci, dgrad ? 1 : 0, p.NTT, p.nchunks);
@@ -1632,8 +1749,8 @@ bool conv_mfma_supported(const Mri3dConvGeom& g, int pass) {
 size_t conv_mfma_workspace_bytes(const Mri3dConvGeom& g, int pass) {
     MfmaFwdPlan p;
     MfmaWgradPlan q;
-    if (pass == MRI3D_PASS_FWD && mfma_fwd_plan(g, false, p)) return p.wp_floats * sizeof(float);
-    if (pass == MRI3D_PASS_DGRAD && mfma_fwd_plan(g, true, p)) return p.wp_floats * sizeof(float);
+    if (pass == MRI3D_PASS_FWD && mfma_fwd_plan(g, false, p)) return std::max(p.wp_floats, p.s_wp_floats) * sizeof(float);
+    if (pass == MRI3D_PASS_DGRAD && mfma_fwd_plan(g, true, p)) return std::max(p.wp_floats, p.s_wp_floats) * sizeof(float);
     if (pass == MRI3D_PASS_WGRAD && mfma_wgrad_plan(g, q)) return q.part_floats * sizeof(float);
     return 0;
 }

@@ -391,6 +391,11 @@ def _conv_wgrad(g, x, dy, w_like, want_bias, dw_out=None, db_out=None):
     return dw, db
 
 
+def _stuffed_wgrad_ok(g):
+    return ((g.kd, g.kh, g.kw) == (3, 3, 3) and (g.sd, g.sh, g.sw) == (2, 2, 2) and (g.pd, g.ph, g.pw) == (1, 1, 1)
+            and (g.dd, g.dh, g.dw) == (1, 1, 1) and g.ci % 8 == 0 and g.co % 4 == 0 and g.x_ld % 4 == 0)
+
+
 class _Conv3dFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias, stride, padding, dilation, stats_holder=None):
@@ -438,7 +443,15 @@ class _Conv3dFn(torch.autograd.Function):
             want_b = ctx.has_bias and ctx.needs_input_grad[2]
             dw_out = _sink_take(wp) if ctx.needs_input_grad[1] else None
             db_out = _sink_take(bp) if want_b else None
-            dw, db = _conv_wgrad(gw, x, dy, w, ctx.has_bias, dw_out, db_out)
+            xw, dyw = x, dy
+            if (_stuffed_wgrad_ok(g) and dy.dtype == x.dtype):
+                # 3x3x3 / stride 2 / pad 1 (modified_3dunet.py:23-38): dW[tap] = sum_o X[2o - 1 + tap] dY[o] is the STRIDE-1 weight
+                # gradient of X against dY spread onto the even voxels of a zero volume — 8x the arithmetic, but on the MFMA
+                # weight-gradient kernel (~100 TFLOP/s) instead of the generic one (4.6 TFLOP/s on the 8 -> 16 layer at 80x96x80)
+                dyw = torch.empty((g.n, g.co, g.di, g.hi, g.wi), dtype=dy.dtype, device=dy.device, memory_format=CL3D).zero_()
+                dyw[:, :, ::2, ::2, ::2].copy_(dy)
+                gw = _conv_geom(x.shape, w.shape, (1, 1, 1), (1, 1, 1), (1, 1, 1), x_ld=g.x_ld, y_ld=g.co, dtype=g.dtype)
+            dw, db = _conv_wgrad(gw, xw, dyw, w, ctx.has_bias, dw_out, db_out)
             dw = _sink_done(wp, dw, dw_out) if ctx.needs_input_grad[1] else None
             db = _sink_done(bp, db, db_out) if want_b else None
         return dx, dw, db, None, None, None, None

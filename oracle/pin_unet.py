@@ -8,7 +8,7 @@ upsampling reproduces those statistics on a T1-like volume, layer by layer; a wr
 downstream of the mistake.
 
     python -m oracle.pin_unet            # all checkpoints x all variants, full 184x220x184 volume  -> tests/golden/unet_pin.json
-                                         # + tests/golden/pseudo_t1_crop.npz (input of the committed CPU test)
+                                         # + tests/golden/mni152_gm_u8.npz (input of the committed CPU test)
 
 Input: a pseudo-T1 built from the reference's grey-matter template (detection/MNI152_T1_1mm_brain_gray.nii.gz, a data file):
 GM 70, enclosed white matter 110, sigma 0.7 blur, z-normalised over the voxels above the mean (TorchIO ZNormalization(mean), as the
@@ -121,18 +121,17 @@ def summarise(sc, layers=None):
 def main():
     sys.path.insert(0, ROOT)
     from oracle import unet_recon
-    torch.set_num_threads(8)
+    torch.set_num_threads(int(os.environ.get("PIN_THREADS", "8")))
     gm = read_nifti(os.path.join(REF, "detection", "MNI152_T1_1mm_brain_gray.nii.gz"))
-    vol = pseudo_t1(gm)
+    # the committed fixture is the template quantised to 8 bits (0.8 MB); everything below is computed from THAT, so that the
+    # CPU test (tests/test_unet_pin.py) rebuilds exactly this input
+    q = np.round(gm / gm.max() * 255).astype(np.uint8)
+    np.savez_compressed(os.path.join(OUT, "mni152_gm_u8.npz"), gm=q)
+    vol = pseudo_t1(q.astype(np.float32) / 255.0)
     print("pseudo-T1", vol.shape, float(vol.min()), float(vol.max()))
-    # input of the committed CPU test: central crop, stored as float16 (the test z-normalises nothing itself)
-    c = [s // 2 for s in vol.shape]
-    crop = vol[c[0] - 48:c[0] + 48, c[1] - 56:c[1] + 56, c[2] - 48:c[2] + 48]
-    np.savez_compressed(os.path.join(OUT, "pseudo_t1_crop.npz"), vol=crop.astype(np.float16))
     x_full = torch.from_numpy(vol)[None, None]
-    x_crop = torch.from_numpy(crop.astype(np.float16).astype(np.float32))[None, None]
     wdir = os.path.join(REF, "segmentation", "weights")
-    results = {"volume": list(vol.shape), "crop": list(crop.shape), "checkpoints": {}}
+    results = {"volume": list(vol.shape), "checkpoints": {}}
     for f in sorted(os.listdir(wdir)):
         if not f.endswith(".pth"):
             continue
@@ -145,14 +144,6 @@ def main():
                 rec, _ = forward_stats(m, x_full, **kw)
             sc = scores(rec)
             entry[vname] = {"all": summarise(sc), "decoder": summarise(sc, "dec"), "per_layer": {k: [round(a, 4), round(b, 4)] for k, (a, b) in sc.items()}}
-        if f == "whole_im_train_seg_parc_epoch_7.pth":   # the checkpoint committed as a fixture: also on the crop
-            crop_entry = {}
-            for vname, kw in VARIANTS.items():
-                with torch.no_grad():
-                    rec, _ = forward_stats(m, x_crop, **kw)
-                sc = scores(rec)
-                crop_entry[vname] = {"all": summarise(sc), "decoder": summarise(sc, "dec")}
-            results["crop_scores_epoch_7"] = crop_entry
         results["checkpoints"][f] = entry
         base = entry["recon (skip first, trilinear, conv-BN-PReLU)"]
         print("%-46s recon: all dm %.3f dv %.3f | decoder dm %.3f dv %.3f" % (f, *base["all"], *base["decoder"]))

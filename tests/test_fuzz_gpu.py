@@ -43,6 +43,26 @@ def test_conv3x3x3_misaligned_channel_slices_fall_back_to_generic_kernels(case, 
     _run_conv_case(case, dtype)
 
 
+# fp32 volumes with fewer than 256 work units go to the wave-per-M-tile kernel (conv_mfma_small_kernel); these ragged shapes
+# have enough batch to stay on the TILED fp32 kernel, so that its border tiles keep their fp32 coverage
+TILED_F32 = [(40, 16, 16, 5, 9, 19, 0, 0, 21), (24, 8, 32, 6, 11, 17, 8, 0, 22), (48, 48, 16, 3, 7, 21, 0, 8, 23)]
+
+
+@pytest.mark.parametrize("case", TILED_F32, ids=lambda c: "n%d_%d-%d_%dx%dx%d_p%d_%d" % c[:8])
+def test_conv3x3x3_ragged_tiles_with_large_batch_stay_on_the_tiled_kernel(case):
+    _run_conv_case(case, torch.float32)
+
+
+# deep-level shapes of Modified3DUNet (batch 1): served by the small-volume kernel in fp32 (1, 2 and 4 N-tiles per wave)
+SMALL = [(1, 64, 64, 20, 24, 20, 0, 0, 31), (1, 128, 128, 10, 12, 10, 0, 0, 32), (1, 128, 64, 20, 24, 20, 0, 0, 33),
+         (1, 32, 32, 40, 48, 40, 0, 0, 34), (2, 24, 48, 7, 5, 9, 8, 8, 35), (1, 16, 16, 3, 3, 3, 0, 0, 36)]
+
+
+@pytest.mark.parametrize("case", SMALL, ids=lambda c: "n%d_%d-%d_%dx%dx%d_p%d_%d" % c[:8])
+def test_conv3x3x3_small_volumes(case):
+    _run_conv_case(case, torch.float32)
+
+
 def _run_conv_case(case, dtype):
     nb, ci, co, d, h, w, pad_in, pad_out, seed = case
     g = torch.Generator().manual_seed(seed)
