@@ -65,6 +65,30 @@ def build(force=False, jobs=4, verbose=True):
     return LIB
 
 
+def build_variant(name, extra_flags, verbose=True):
+    """Tuning builds for tools/ only (A/B kernels, ablations): libmri3d_hip_<name>.so next to the product library, compiled with
+    -DMRI3D_TUNING plus `extra_flags`.  The product package never loads these; tools/conv_bench.py --lib does."""
+    obj_dir = os.path.join(CSRC, "build_" + name)
+    os.makedirs(obj_dir, exist_ok=True)
+    lib = os.path.join(HERE, "libmri3d_hip_%s.so" % name)
+
+    def one(src):
+        obj = os.path.join(obj_dir, src.replace(".hip", ".o"))
+        r = subprocess.run([HIPCC] + FLAGS + ["-DMRI3D_TUNING"] + list(extra_flags) + ["-c", os.path.join(CSRC, src), "-o", obj],
+                           capture_output=True, text=True, timeout=900)
+        if r.returncode != 0:
+            raise RuntimeError("hipcc failed for %s:\n%s" % (src, r.stderr[-3000:]))
+        return obj
+    with ThreadPoolExecutor(max_workers=4) as ex:
+        objs = list(ex.map(one, SOURCES))
+    r = subprocess.run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib] + objs, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("link failed:\n%s" % r.stderr[-3000:])
+    if verbose:
+        print("built", lib)
+    return lib
+
+
 def build_host_sanitizer(verbose=True):
     """Host-only AddressSanitizer + UBSan build of the library's host code (argument validation, plan / dispatch selection,
     workspace sizing) linked with tests/native/host_sanitizer_driver.cpp into ONE executable; the sanitizers instrument the host
@@ -107,7 +131,10 @@ def build_host_sanitizer(verbose=True):
 
 
 if __name__ == "__main__":
-    if "--host-sanitizer" in sys.argv:
+    if "--variant" in sys.argv:
+        i = sys.argv.index("--variant")
+        build_variant(sys.argv[i + 1], sys.argv[i + 2:])
+    elif "--host-sanitizer" in sys.argv:
         print(build_host_sanitizer())
     else:
         build(force="--force" in sys.argv)

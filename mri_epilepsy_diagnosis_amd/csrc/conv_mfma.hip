@@ -310,9 +310,24 @@ conv_mfma_fwd2_kernel(const T* __restrict__ x, const float* __restrict__ wp, con
                 const int cb = tg % 3, nb = (tg + 2) % 3;
                 const int u = tg < 12 ? tg / 3 : tg - 8, ufirst = u < 4 ? 3 * u : u + 8, ng = u < 4 ? 3 : 1;
                 const int kh = tg - ufirst;   // row shift inside the class (0 for the single-group units)
+                // MRI3D_EXPERIMENT_*: timing ablations of tuning builds (python -m mri_epilepsy_diagnosis_amd.build --variant ...;
+                // results are wrong).  Measured on 48->16, 2 x 160x192x160 fp32 (profiles/r02_fwd_ablation.txt): all of it
+                // 121.1 TFLOP/s, without the staging 130.9, without the weight loads 123.4, without any memory instruction
+                // in the loop 137.8, without the per-chunk barrier 120.5 (no effect).
+#if !defined(MRI3D_EXPERIMENT_NO_STAGING)
                 if (tg < kStg) sq[tg & 3] = stage_load(nxt, fbn, tg);  // next chunk: global -> regs (unconditional)
+#endif
+#if !defined(MRI3D_EXPERIMENT_NO_WLOAD)
                 if (tg + 2 < TG) bq[nb][0] = *reinterpret_cast<const f32x4*>(wt + (size_t)(tg + 2) * wstep);
+#else
+                if (tg + 2 < TG) bq[nb][0] = bq[cb][0];
+#endif
+#if !defined(MRI3D_EXPERIMENT_NO_STAGING)
                 if (tg >= 3 && tg - 3 < kStg) stage_store(bufn, tg - 3, sq[(tg - 3) & 3]);  // regs -> LDS
+#endif
+#if defined(MRI3D_EXPERIMENT_NO_AFRAG)
+                if (false)
+#endif
                 if (u + 1 < NU) {   // this group's share of the next unit's fragments
                     const int nu = u + 1, nfirst = nu < 4 ? 3 * nu : nu + 8, nf = nu < 4 ? TH + 2 : TH;
                     const int on = a_off(nfirst);
@@ -454,7 +469,9 @@ conv_mfma_fwd2_kernel(const T* __restrict__ x, const float* __restrict__ wp, con
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) acc[m][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
         }
+#if !defined(MRI3D_EXPERIMENT_NO_CHUNK_BARRIER)   // tuning builds only: timing ablation, results are wrong without it
         __syncthreads();  // buffer (it+1)&1 is complete; buffer it&1 may be overwritten from the next iteration on
+#endif
         cur = nxt;
     }
     if constexpr (STATS) {   // the loop ended with a barrier: combine the four waves in a fixed order, one partial per workgroup

@@ -11,6 +11,10 @@ from mri_epilepsy_diagnosis_amd import _lib, ops  # noqa: E402
 
 
 def main():
+    if "--lib" in sys.argv:   # a tuning build (python -m mri_epilepsy_diagnosis_amd.build --variant NAME -D...), tools only
+        i = sys.argv.index("--lib")
+        _lib.LIB_PATH = os.path.abspath(sys.argv[i + 1])
+        del sys.argv[i:i + 2]
     ci, co, d, h, w = (int(a) for a in sys.argv[1:6])
     n = int(sys.argv[6]) if len(sys.argv) > 6 else 2
     reps = int(sys.argv[7]) if len(sys.argv) > 7 else 10
