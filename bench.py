@@ -287,19 +287,22 @@ def main():
             achieved, peak, unit, bound = work["flops"] / avg_s / 1e12, peak_tflops, "TFLOP/s", "mfma"
         else:
             achieved, peak, unit, bound = work["bytes"] / avg_s / 1e9, PEAK_HBM_GBS, "GB/s", "hbm"
-        # HBM traffic per launch of the dominant kernel: PMC counters cannot be read from inside this process, so the figure
-        # comes from the committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of the same kernel on the same
-        # geometry (profiles/r01_hbm_traffic_48_16.json, collected by tools/collect_traffic.py); null if not collected.
-        traffic = None
+        # HBM-side traffic per launch of the dominant kernel.  PMC counters cannot be read from inside this process, so this is
+        # NOT a measurement of this run: it is the committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE record (separate passes,
+        # tools/pmc_conv.sh) of the same kernel on the same geometry, with FETCH_SIZE x 2 as calibrated on this library's
+        # access shapes (profiles/r02_fetch_size_calibration.txt).  `traffic_source` says so in the line itself; null if the
+        # dominant operator has no record.
+        traffic, traffic_source = None, None
         try:
-            with open(os.path.join(ROOT, "profiles", "r01_hbm_traffic_48_16.json")) as f:
-                rec = json.load(f).get(dom_tag)
+            with open(os.path.join(ROOT, "profiles", "r02_hbm_traffic_48_16.json")) as f:
+                rec = json.load(f).get(dom_tag.replace(" +bn-stats", ""))
             if rec:
                 traffic = round(rec["traffic_bytes"])
+                traffic_source = "profiles/r02_hbm_traffic_48_16.json (rocprofv3 --pmc, separate run of this kernel and geometry; 2 x FETCH_SIZE + WRITE_SIZE)"
         except (OSError, ValueError):
             pass
         roofline = {"bound": bound, "achieved": round(achieved, 3), "peak": peak, "unit": unit,
-                    "frac": round(achieved / peak, 4), "traffic": traffic, "kernel": dom_tag,
+                    "frac": round(achieved / peak, 4), "traffic": traffic, "traffic_source": traffic_source, "kernel": dom_tag,
                     "avg_launch_ms": round(avg_s * 1e3, 4), "share_of_timed_ops": round(dom["ms"] / total_ms, 4)}
         top = sorted(agg.items(), key=lambda kv: -kv[1]["ms"])[:int(os.environ.get("MRI3D_BENCH_TOP", "12"))]
         sys.stderr.write("per-operator device time over %d %s (events on the launch stream):\n"
