@@ -511,7 +511,8 @@ conv_mfma_small_kernel(const float* __restrict__ x, const float* __restrict__ wp
     const int h0 = (int)(t % H);
     t /= H;
     const int d0 = (int)(t % D);
-    const float* xv = x + vc * x_ld + 4 * kq;                      // this lane's voxel, its k-group's first channel
+    const float* x0 = x + vc * x_ld;                               // this lane's voxel: always a readable 16 bytes (Kc >= 8)
+    const float* xv = x0 + 4 * kq;                                 // ... its k-group's first channel (may lie past Kc: see cok)
     const int nchunks = (Kc + 15) / 16;
     const int nt0 = ntb * NT;
 
@@ -532,11 +533,11 @@ conv_mfma_small_kernel(const float* __restrict__ x, const float* __restrict__ wp
                 const bool ok = okh && (unsigned)(w0 + kw - 1) < (unsigned)W;
                 const int tap = (kd * 3 + kh) * 3 + kw;
                 const int64_t eoff = ((int64_t)((kd - 1) * H + (kh - 1)) * W + (kw - 1)) * x_ld;
-                const float* src = ok ? xv + eoff : xv;            // clamped address, zeroed below
+                const float* src = ok ? xv + eoff : x0;            // clamped address, zeroed below
                 const float* wt = wbase + (size_t)tap * wtap;
                 for (int ch = 0; ch < nchunks; ++ch) {
                     const bool cok = ok && ch * 16 + 4 * kq < Kc;   // Kc % 4 == 0 (host)
-                    float4 a = *reinterpret_cast<const float4*>(cok ? src + ch * 16 : xv);
+                    float4 a = *reinterpret_cast<const float4*>(cok ? src + ch * 16 : x0);
                     if (!cok) a = make_float4(0.f, 0.f, 0.f, 0.f);
                     const float av[4] = {a.x, a.y, a.z, a.w};
 #pragma unroll

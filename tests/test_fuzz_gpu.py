@@ -63,6 +63,19 @@ def test_conv3x3x3_small_volumes(case):
     _run_conv_case(case, torch.float32)
 
 
+# one-N-tile passes with >= 256 (tile, N-block) units take the 64-byte-chunk kernel (conv_mfma3.hip, 8x8x16 tiles): ragged tile
+# borders in every dimension, 1 / 2 / 3 chunks (fp32 16 channels, bf16 32 channels per chunk; bf16 48 = a half-empty second chunk),
+# three N-blocks (the 48-channel data gradient), pitched inputs and outputs
+LARGE_BATCH_CASES = [(64, 16, 16, 9, 13, 21, 0, 0, 41), (72, 48, 16, 5, 9, 19, 0, 8, 42), (96, 16, 48, 3, 10, 17, 16, 0, 43),
+            (40, 32, 16, 11, 9, 33, 8, 8, 44), (260, 16, 16, 2, 3, 5, 0, 0, 45)]
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
+@pytest.mark.parametrize("case", LARGE_BATCH_CASES, ids=lambda c: "n%d_%d-%d_%dx%dx%d_p%d_%d" % c[:8])
+def test_conv3x3x3_many_small_volumes(case, dtype):
+    _run_conv_case(case, dtype)
+
+
 def _run_conv_case(case, dtype):
     nb, ci, co, d, h, w, pad_in, pad_out, seed = case
     g = torch.Generator().manual_seed(seed)

@@ -581,7 +581,9 @@ def test_bench_multi_rank_path_rehearsed_on_one_gpu():
     assert out["n_gpus"] == 2 and out["steps"] == 2 and out["warmup"] == 1 and out["scaling"] == "weak"
     assert out["config"]["global_batch"] == 4 and out["config"]["parallelism"] == "dp2"
     assert out["value"] > 0 and abs(out["value"] - 4 * 2 / (out["ms_per_step"] * 2 / 1e3)) < 1e-2 * out["value"]
-    assert "cpu_baseline" not in out and out["roofline"]["frac"] > 0
+    # two processes time-slice the one card here, so WHICH operator collects the most event time (and its rate) is arbitrary:
+    # only the shape of the roofline object is checked
+    assert "cpu_baseline" not in out and out["roofline"]["frac"] >= 0 and out["roofline"]["kernel"]
     assert out["ranks_seen"] == 2 and out["backend"] == "gloo"
 
 

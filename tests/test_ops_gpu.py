@@ -489,7 +489,8 @@ def test_surface_element_lists_and_order_metrics_bit_exact():
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
 @pytest.mark.parametrize("case", [(2, 16, 16, 9, 13, 21, True), (1, 48, 16, 8, 16, 32, True), (2, 8, 32, 5, 8, 16, False),
-                                  (1, 32, 64, 4, 9, 17, True), (1, 16, 48, 6, 7, 19, True)],
+                                  (1, 32, 64, 4, 9, 17, True), (1, 16, 48, 6, 7, 19, True),
+                                  (64, 16, 16, 9, 13, 21, True), (90, 48, 16, 3, 9, 17, False), (88, 16, 48, 5, 7, 19, True)],
                          ids=lambda c: "n%d_%d-%d_%dx%dx%d_b%d" % c)
 def test_batchnorm_statistics_from_the_conv_epilogue_equal_the_statistics_pass(case, dtype):
     """conv3d(bn_stats=True) accumulates the BatchNorm batch statistics in the MFMA kernel's epilogue (float64 partials per
@@ -520,9 +521,13 @@ def test_batchnorm_statistics_from_the_conv_epilogue_equal_the_statistics_pass(c
         if name == "dbias":      # analytically zero (a bias in front of a batch-statistics BatchNorm): both are rounding noise
             scale = res[0][4].abs().max().item()
         # bf16 gradients: a statistic that moves in its 5th digit flips ReLU decisions of near-zero pre-activations, and each flip
-        # moves individual dx / dw entries by one bf16-rounded term
-        t = 8e-2 if (dtype == torch.bfloat16 and name in ("dx", "dw", "dgamma", "dbeta", "dbias")) else tol
-        assert (a - r).abs().max().item() <= t * (scale + 1e-6), (name, (a - r).abs().max().item(), scale)
+        # moves individual dx / dw entries by one bf16-rounded term: the more voxels, the larger the largest single such move, so
+        # those are held to a relative L2 bound (the flips are sparse) and a loose max bound
+        if dtype == torch.bfloat16 and name in ("dx", "dw", "dgamma", "dbeta", "dbias"):
+            assert (a - r).norm().item() <= 2e-2 * (r.norm().item() + scale), (name, (a - r).norm().item(), r.norm().item())
+            assert (a - r).abs().max().item() <= 0.2 * (scale + 1e-6), (name, (a - r).abs().max().item(), scale)
+            continue
+        assert (a - r).abs().max().item() <= tol * (scale + 1e-6), (name, (a - r).abs().max().item(), scale)
     # against torch's own batch statistics (fp32 only: exact semantics check incl. the unbiased running variance)
     if dtype == torch.float32:
         yr = F.conv3d(x.float().cpu(), wt.cpu(), b.cpu() if has_bias else None, padding=1)
