@@ -123,6 +123,27 @@ __global__ void pack_w_mfma_bf16_kernel(const float* __restrict__ w, bf16_t* __r
 //       of one voxel per lane and the epilogue is a fully coalesced 16-byte store per lane (1 KiB per wave).
 constexpr int kStg = (HVOX * 2 + 255) / 256;  // 16-byte staging pieces per lane per 8-channel chunk (9)
 
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+#ifndef MRI3D_DMA_PPT
+#define MRI3D_DMA_PPT 1   // DMA pieces issued per tap group (9 pieces per chunk)
+#endif
+
+// One LDS-DMA piece (`buffer_load_dwordx4 ... offen lds`): lane l's 16 bytes at byte offset `voff` of the buffer resource `rs`
+// land at LDS byte address lds_dst + 16*l (lds_dst wave-uniform: a wave-instruction fills 1 KiB); an offset >= num_records
+// writes ZEROS.  No VGPR destination, no ds_write.  Semantics probed on the hardware by tools/microbench/lds_dma_probe.hip
+// (incl. LDS addresses above 64 KiB).  The load is invisible to hipcc's s_waitcnt bookkeeping: the kernel waits for its DMA
+// pieces itself (a counted vmcnt in front of the chunk barrier); hipcc's own counts stay conservative-correct because VMEM
+// returns in order.  M0 (the LDS base of the DMA) is compiler-reserved: saved and restored inside the statement.
+__device__ __forceinline__ void lds_dma16(unsigned voff, i32x4 rs, unsigned lds_dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(voff), "s"(rs), "s"(lds_dst)
+                 : "memory");
+}
+constexpr unsigned kDmaOob = 0xffffff80u;      // >= kDmaRecords: an out-of-volume piece (zeros)
+constexpr unsigned kDmaRecords = 0xffffff00u;  // num_records of the per-item resource (its base is the item's halo origin)
+
 // T = float: 8-channel chunks, four 16x16x4 fp32 MFMAs per tap group.  T = bf16_t: the SAME byte geometry (a 32-byte voxel
 // slice = 16 channels, 16-byte pieces, identical staging and LDS addressing) with one v_mfma_f32_16x16x32_bf16 per tap
 // group; the kernel is then bound by the LDS operand reads (the bf16 3x3x3 layers are memory-bound).
@@ -186,18 +207,15 @@ conv_mfma_fwd2_kernel(const T* __restrict__ x, const float* __restrict__ wp, con
         const int wx = v % HW, t2 = v / HW;
         srel[j] = ((t2 / HH) << 16) | ((t2 % HH) << 8) | wx;
     }
-    // ... and its element offset from the tile's halo origin voxel (d0-1, h0-1, w0-1), so that a piece's address is a
-    // wave-uniform base + a 32-bit lane offset: no per-piece integer multiplies, clamps or 64-bit arithmetic (the ISA of
-    // the previous version spent 52 v_mul_lo_u32 + 35 64-bit mads per chunk on them — quarter-rate VALU work that the
-    // fp32 MFMA does not hide).  Out-of-volume pieces read the tile's first output voxel instead (always valid) and are
-    // zeroed when they are written to LDS.
+    // ... and its BYTE offset from the item's halo origin (voxel (d0-1, h0-1, w0-1), channel ch*CK): the DMA's buffer resource
+    // is based at that origin, so an in-volume piece's offset is this per-lane constant — no per-piece integer multiplies,
+    // clamps or 64-bit arithmetic — and an out-of-volume piece gets the out-of-range offset that makes the DMA write zeros.
     unsigned frel[kStg];
 #pragma unroll
     for (int j = 0; j < kStg; ++j) {
         const int r = srel[j];
-        frel[j] = (unsigned)((((r >> 16) * H + ((r >> 8) & 0xff)) * W + (r & 0xff)) * x_ld + PE * (tid & 1));
+        frel[j] = (unsigned)((((r >> 16) * H + ((r >> 8) & 0xff)) * W + (r & 0xff)) * x_ld + PE * (tid & 1)) * (unsigned)sizeof(T);
     }
-    const unsigned forig = (unsigned)(((H + 1) * W + 1) * x_ld);
 
     struct Item { int n, d0, h0, w0, nt0, ch; };
     auto decode = [&](int it) -> Item {
@@ -214,47 +232,71 @@ conv_mfma_fwd2_kernel(const T* __restrict__ x, const float* __restrict__ wp, con
         r.n = tile / tilesD;
         return r;
     };
-    // The load is UNCONDITIONAL (clamped address); out-of-volume pieces are zeroed only when they are written to LDS
-    // three tap groups later.  A load inside a branch makes hipcc treat it as "maybe not issued" and shorten every
-    // later vmcnt wait of the B ring to cover it (12 % measured); zeroing right after the load forces vmcnt(0).
-    unsigned okmask = 0;
-    auto halo_origin = [&](const Item& it) -> const T* {   // wave-uniform; only dereferenced at in-volume offsets
-        return x + (((((int64_t)it.n * D + it.d0 - 1) * H + it.h0 - 1) * W + it.w0 - 1) * x_ld + it.ch * CK);
+    const unsigned lds_wave = __builtin_amdgcn_readfirstlane((unsigned)(size_t)lds + (unsigned)wv * 1024u);
+    // Stage one item (a 32-byte channel chunk of a halo tile) into LDS buffer `bsel`: kStg DMA pieces per lane, piece j of lane
+    // `tid` = 16-byte piece j*256 + tid of the [halo voxel][32 B] image — lane-linear, which is what an LDS-DMA writes.
+    // Tiles whose halo lies inside the volume (70 % at 160x192x160) take the wave-uniform fast path: the offsets are the
+    // per-lane constants, no VALU work at all.  (Pieces past the tile's end alias voxel 0 and land in the buffer's padding.)
+    struct Stage { i32x4 rs; unsigned dst; bool interior, on; };
+    auto stage_open = [&](const Item& it, int bsel, bool on) -> Stage {
+        Stage st;
+#if defined(MRI3D_EXPERIMENT_SAME_TILE)   // every item stages the same (interior) tile: all pieces are L2 hits, no fabric traffic
+        const unsigned long long org = (unsigned long long)(x + ((((int64_t)(TD - 1) * H + TH - 1) * W + TW - 1) * x_ld + it.ch * CK));
+#else
+        const unsigned long long org =
+            (unsigned long long)(x + (((((int64_t)it.n * D + it.d0 - 1) * H + it.h0 - 1) * W + it.w0 - 1) * x_ld + it.ch * CK));
+#endif
+        // raw buffer resource: base (48 bits), stride 0, num_records, gfx9 raw-dword format
+        st.rs[0] = __builtin_amdgcn_readfirstlane((int)(unsigned)(org & 0xffffffffu));
+        st.rs[1] = __builtin_amdgcn_readfirstlane((int)(unsigned)((org >> 32) & 0xffffu));
+        st.rs[2] = (int)kDmaRecords;
+        st.rs[3] = 0x00020000;
+        st.dst = lds_wave + (unsigned)bsel * (unsigned)(BUF * 4);
+        st.interior = it.d0 >= 1 && it.d0 + TD < D && it.h0 >= 1 && it.h0 + TH < H && it.w0 >= 1 && it.w0 + TW < W &&
+                      (it.ch + 1) * CK <= Kc;
+        st.on = on;
+        return st;
     };
-    auto stage_load = [&](const Item& it, const T* fb, int j) -> float4 {
-        const int r = srel[j];
-        const int gd = it.d0 - 1 + (r >> 16), gh = it.h0 - 1 + ((r >> 8) & 0xff), gw = it.w0 - 1 + (r & 0xff);
-        const bool ok = (unsigned)gd < (unsigned)D && (unsigned)gh < (unsigned)H && (unsigned)gw < (unsigned)W &&
-                        it.ch * CK + PE * (tid & 1) < Kc;
-        okmask = ok ? (okmask | (1u << j)) : (okmask & ~(1u << j));
-        if constexpr (NT == 1) {
-            return *reinterpret_cast<const float4*>(fb + (ok ? frel[j] : forig));
-        } else {   // NT = 2 has no 9 registers to spare for frel (it spills): clamped coordinates, 64-bit address arithmetic
-            const int c0 = it.ch * CK + PE * (tid & 1);
-            const int cd = min(max(gd, 0), D - 1), chh = min(max(gh, 0), H - 1), cw = min(max(gw, 0), W - 1);
-            return *reinterpret_cast<const float4*>(x + ((((int64_t)it.n * D + cd) * H + chh) * W + cw) * x_ld +
-                                                    (c0 < Kc ? c0 : 0));
+    auto stage_piece = [&](const Item& it, const Stage& st, int j) {   // wave-uniform branches only
+        if (!st.on) return;
+        if (st.interior) {
+            lds_dma16(frel[j], st.rs, st.dst + j * 4096);
+        } else {
+            const int r = srel[j];
+            const int gd = it.d0 - 1 + (r >> 16), gh = it.h0 - 1 + ((r >> 8) & 0xff), gw = it.w0 - 1 + (r & 0xff);
+            const bool ok = (unsigned)gd < (unsigned)D && (unsigned)gh < (unsigned)H && (unsigned)gw < (unsigned)W &&
+                            it.ch * CK + PE * (tid & 1) < Kc;
+            lds_dma16(ok ? frel[j] : kDmaOob, st.rs, st.dst + j * 4096);
         }
     };
-    auto stage_store = [&](float* buf, int j, const float4& val) {
-        const bool ok = (okmask >> j) & 1u;
-        float4 v2;
-        v2.x = ok ? val.x : 0.f;
-        v2.y = ok ? val.y : 0.f;
-        v2.z = ok ? val.z : 0.f;
-        v2.w = ok ? val.w : 0.f;
-        *reinterpret_cast<float4*>(buf + (j * 256 + tid) * 4) = v2;
+    // pieces issued in front of tap group tg: kPpt per group, so that a wave's issue slots (~60-180 cycles per piece) are
+    // spread behind MFMAs instead of delaying the chunk's first fragments
+    constexpr int kPpt = MRI3D_DMA_PPT;
+    auto stage_group = [&](const Item& it, const Stage& st, int tg) {
+#pragma unroll
+        for (int j = tg * kPpt; j < (tg + 1) * kPpt && j < kStg; ++j) stage_piece(it, st, j);
     };
+    auto weights_of = [&](const Item& it) -> const float* {
+        return wp + ((size_t)it.ch * TG * NTT + it.nt0) * 256 + lane * 4;
+    };
+    const size_t wstep = (size_t)NTT * 256;
 
-    // prologue: item 0 -> buffer 0
+    // prologue: item 0 -> buffer 0 (and, one N-tile: all 14 weight fragments of its chunk)
     Item cur = decode(0);
-    {
-        float4 tmp[kStg];
+    f32x4 bqa[NT == 1 ? TG : 1];   // NT = 1: the weight fragments of the WHOLE chunk; fragment tg is re-loaded for the next item
+                                   // right after tap group tg has used it — a full chunk of latency cover, and no weight load
+                                   // ever queues behind the DMA pieces it does not depend on (VMEM returns in order)
+    if constexpr (NT == 1) {
+        const float* w0p = weights_of(cur);
 #pragma unroll
-        for (int j = 0; j < kStg; ++j) tmp[j] = stage_load(cur, halo_origin(cur), j);
-#pragma unroll
-        for (int j = 0; j < kStg; ++j) stage_store(lds, j, tmp[j]);
+        for (int tg = 0; tg < TG; ++tg) bqa[tg] = *reinterpret_cast<const f32x4*>(w0p + (size_t)tg * wstep);
     }
+    {
+        const Stage st0 = stage_open(cur, 0, true);
+#pragma unroll
+        for (int j = 0; j < kStg; ++j) stage_piece(cur, st0, j);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
     f32x4 acc[TH][NT];
@@ -273,7 +315,6 @@ conv_mfma_fwd2_kernel(const T* __restrict__ x, const float* __restrict__ wp, con
 
     for (int it = 0; it < nitems; ++it) {
         const float* bufc = lds + (it & 1) * BUF;
-        float* bufn = lds + ((it + 1) & 1) * BUF;
         const bool has_next = it + 1 < nitems;
         Item nxt = cur;
         // the next item is the next chunk of the same tile, or chunk 0 of this workgroup's next tile: only the second case
@@ -282,22 +323,19 @@ conv_mfma_fwd2_kernel(const T* __restrict__ x, const float* __restrict__ wp, con
             if (cur.ch + 1 < nchunks) nxt.ch = cur.ch + 1;
             else nxt = decode(it + 1);
         }
-        const T* fbn = halo_origin(nxt);
-
-        const float* wt = wp + ((size_t)cur.ch * TG * NTT + cur.nt0) * 256 + lane * 4;
-        const size_t wstep = (size_t)NTT * 256;
-        f32x4 bq[3][NT];
-        float4 sq[4];
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) {
-            bq[0][nt] = *reinterpret_cast<const f32x4*>(wt + nt * 256);
-            bq[1][nt] = *reinterpret_cast<const f32x4*>(wt + wstep + nt * 256);
-        }
+        // MRI3D_EXPERIMENT_*: timing ablations of tuning builds (python -m mri_epilepsy_diagnosis_amd.build --variant ...;
+        // results are wrong): see DESIGN.md §4.2 for the measured table.
         if constexpr (NT == 1) {
             // One N-tile: every A-fragment feeds a single MFMA chain, so the LDS reads are the largest non-MFMA cost.  The tap
             // groups come in UNITS: four classes of three groups that differ only by one halo row (pair_tap), then groups 12
             // and 13.  A class needs 10 row fragments (rows 0..9 of its kh = 0 group; group kh, output row m uses row m + kh)
             // instead of 3 x 8; the next unit's fragments are fetched while this unit is multiplied (two register sets).
+#if !defined(MRI3D_EXPERIMENT_NO_STAGING)
+            const Stage stn = stage_open(nxt, (it + 1) & 1, has_next);   // the next chunk: 9 DMA pieces per lane, landed by the barrier
+#else
+            const Stage stn = stage_open(nxt, (it + 1) & 1, false);
+#endif
+            const float* wtn = weights_of(nxt);             // (the last item re-reads its own: the loads stay unconditional)
             constexpr int NU = 6;
             f32x4 fr[2][TH + 2];
             {
@@ -307,23 +345,11 @@ conv_mfma_fwd2_kernel(const T* __restrict__ x, const float* __restrict__ wp, con
             }
 #pragma unroll
             for (int tg = 0; tg < TG; ++tg) {
-                const int cb = tg % 3, nb = (tg + 2) % 3;
                 const int u = tg < 12 ? tg / 3 : tg - 8, ufirst = u < 4 ? 3 * u : u + 8, ng = u < 4 ? 3 : 1;
                 const int kh = tg - ufirst;   // row shift inside the class (0 for the single-group units)
-                // MRI3D_EXPERIMENT_*: timing ablations of tuning builds (python -m mri_epilepsy_diagnosis_amd.build --variant ...;
-                // results are wrong).  Measured on 48->16, 2 x 160x192x160 fp32 (profiles/r02_fwd_ablation.txt): all of it
-                // 121.1 TFLOP/s, without the staging 130.9, without the weight loads 123.4, without any memory instruction
-                // in the loop 137.8, without the per-chunk barrier 120.5 (no effect).
-#if !defined(MRI3D_EXPERIMENT_NO_STAGING)
-                if (tg < kStg) sq[tg & 3] = stage_load(nxt, fbn, tg);  // next chunk: global -> regs (unconditional)
-#endif
+                stage_group(nxt, stn, tg);
 #if !defined(MRI3D_EXPERIMENT_NO_WLOAD)
-                if (tg + 2 < TG) bq[nb][0] = *reinterpret_cast<const f32x4*>(wt + (size_t)(tg + 2) * wstep);
-#else
-                if (tg + 2 < TG) bq[nb][0] = bq[cb][0];
-#endif
-#if !defined(MRI3D_EXPERIMENT_NO_STAGING)
-                if (tg >= 3 && tg - 3 < kStg) stage_store(bufn, tg - 3, sq[(tg - 3) & 3]);  // regs -> LDS
+                if (tg >= 1) bqa[tg - 1] = *reinterpret_cast<const f32x4*>(wtn + (size_t)(tg - 1) * wstep);   // next item's
 #endif
 #if defined(MRI3D_EXPERIMENT_NO_AFRAG)
                 if (false)
@@ -340,7 +366,7 @@ conv_mfma_fwd2_kernel(const T* __restrict__ x, const float* __restrict__ wp, con
                 if constexpr (kBf16) {
 #pragma unroll
                     for (int m = 0; m < TH; ++m)
-                        acc[m][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, bq[cb][0]),
+                        acc[m][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, bqa[tg]),
                                                                             __builtin_bit_cast(bf16x8_t, fr[u & 1][m + kh]),
                                                                             acc[m][0], 0, 0, 0);
                 } else {
@@ -350,12 +376,26 @@ conv_mfma_fwd2_kernel(const T* __restrict__ x, const float* __restrict__ wp, con
                     for (int m = 0; m < TH; m += 2)
 #pragma unroll
                         for (int s = 0; s < 4; ++s) {
-                            acc[m][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(bq[cb][0][s], fr[u & 1][m + kh][s], acc[m][0], 0, 0, 0);
-                            acc[m + 1][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(bq[cb][0][s], fr[u & 1][m + 1 + kh][s], acc[m + 1][0], 0, 0, 0);
+                            acc[m][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(bqa[tg][s], fr[u & 1][m + kh][s], acc[m][0], 0, 0, 0);
+                            acc[m + 1][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(bqa[tg][s], fr[u & 1][m + 1 + kh][s], acc[m + 1][0], 0, 0, 0);
                         }
                 }
             }
+#if !defined(MRI3D_EXPERIMENT_NO_WLOAD)
+            bqa[TG - 1] = *reinterpret_cast<const f32x4*>(wtn + (size_t)(TG - 1) * wstep);
+#endif
         } else {
+        // Two N-tiles: a 3-deep ring of weight fragments (two tap groups of lead).  The ring is primed BEFORE the DMA pieces are
+        // issued, so that the first tap group does not wait for them; the loads of tap groups 2.. queue behind the pieces,
+        // which have two tap groups (fp32: 3 us) to land.
+        const float* wt = weights_of(cur);
+        f32x4 bq[3][NT];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            bq[0][nt] = *reinterpret_cast<const f32x4*>(wt + nt * 256);
+            bq[1][nt] = *reinterpret_cast<const f32x4*>(wt + wstep + nt * 256);
+        }
+        const Stage stn = stage_open(nxt, (it + 1) & 1, has_next);
         f32x4 aq[2][TH];
         {
             const int o0 = a_off(0);
@@ -365,13 +405,12 @@ conv_mfma_fwd2_kernel(const T* __restrict__ x, const float* __restrict__ wp, con
 #pragma unroll
         for (int tg = 0; tg < TG; ++tg) {
             const int cb = tg % 3, nb = (tg + 2) % 3, ac = tg & 1, an = (tg + 1) & 1;
-            if (tg < kStg) sq[tg & 3] = stage_load(nxt, fbn, tg);  // next chunk: global -> regs (unconditional)
+            stage_group(nxt, stn, tg);
             if (tg + 2 < TG) {
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt)
                     bq[nb][nt] = *reinterpret_cast<const f32x4*>(wt + (size_t)(tg + 2) * wstep + nt * 256);
             }
-            if (tg >= 3 && tg - 3 < kStg) stage_store(bufn, tg - 3, sq[(tg - 3) & 3]);  // regs -> LDS
             if (tg + 1 < TG) {
                 const int o1 = a_off(tg + 1);
 #pragma unroll
@@ -413,6 +452,10 @@ conv_mfma_fwd2_kernel(const T* __restrict__ x, const float* __restrict__ wp, con
                             if (co + 1 < Nc) bv.y = bias[co + 1];
                             if (co + 2 < Nc) bv.z = bias[co + 2];
                             if (co + 3 < Nc) bv.w = bias[co + 3];
+                            // consume the loads HERE on every path: a bias register still "pending" at the loop's back edge
+                            // (no row of this lane in the volume) makes hipcc wait vmcnt(0) at its next reuse — at the top
+                            // of the next item, right behind the freshly issued DMA pieces
+                            asm volatile("" ::"v"(bv.x), "v"(bv.y), "v"(bv.z), "v"(bv.w));
                         }
                         const int ow = cur.w0 + li;
 #pragma unroll
@@ -469,6 +512,9 @@ conv_mfma_fwd2_kernel(const T* __restrict__ x, const float* __restrict__ wp, con
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) acc[m][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
         }
+        // The DMA pieces of the next item are OLDER than the >= 12 weight loads issued after them in this iteration, and VMEM
+        // returns in order: at most 6 operations outstanding means every piece has landed in LDS.
+        asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
 #if !defined(MRI3D_EXPERIMENT_NO_CHUNK_BARRIER)   // tuning builds only: timing ablation, results are wrong without it
         __syncthreads();  // buffer (it+1)&1 is complete; buffer it&1 may be overwritten from the next iteration on
 #endif
