@@ -46,9 +46,6 @@ int conv_pointwise_wgrad(const Mri3dConvGeom& g, const void* x, const void* dy, 
 
 // the MFMA kernels move 16-byte pieces: a pitched channel slice whose base is not 16-byte aligned (legal for the generic
 // kernels) must not be routed to them
-static inline bool aligned16(const void* a, const void* b = nullptr, const void* c = nullptr) {
-    return ((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(b) | reinterpret_cast<uintptr_t>(c)) & 15) == 0;
-}
 
 static int conv_check(const Mri3dConvGeom* g, const char* who) {
     MRI3D_REQUIRE(g != nullptr, MRI3D_EINVAL, "%s: null geometry", who);

@@ -83,6 +83,11 @@ inline bool aligned_vec4(int dtype, const void* a, const void* b = nullptr, cons
     return ((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(b) | reinterpret_cast<uintptr_t>(c)) & m) == 0;
 }
 
+// every given pointer 16-byte aligned (dwordx4 accesses, LDS-DMA pieces)
+inline bool aligned16(const void* a, const void* b = nullptr, const void* c = nullptr) {
+    return ((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(b) | reinterpret_cast<uintptr_t>(c)) & 15) == 0;
+}
+
 // Run `body` with `T` bound to the storage type of `dtype`.
 #define MRI3D_DISPATCH_DTYPE(dtype, T, ...)  \
     do {                                     \

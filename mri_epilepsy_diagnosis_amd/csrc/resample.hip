@@ -18,7 +18,11 @@ struct V {
     float v[VEC];
     template <typename T>
     __device__ __forceinline__ void load(const T* p) {
-        if (VEC == 4) {
+        if constexpr (VEC == 8) {   // bf16 only: one 16-byte access (8-byte ones leave these kernels at half the fp32 rate)
+            const bf16x8_t t = *reinterpret_cast<const bf16x8_t*>(p);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = (float)t[j];
+        } else if constexpr (VEC == 4) {
             float4 t = ldf4(p);
             v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
         } else {
@@ -27,7 +31,12 @@ struct V {
     }
     template <typename T>
     __device__ __forceinline__ void store(T* p) const {
-        if (VEC == 4) stf4(p, make_float4(v[0], v[1], v[2], v[3]));
+        if constexpr (VEC == 8) {
+            bf16x8_t o;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o[j] = (bf16_t)v[j];
+            *reinterpret_cast<bf16x8_t*>(p) = o;
+        } else if constexpr (VEC == 4) stf4(p, make_float4(v[0], v[1], v[2], v[3]));
         else stf(p, v[0]);
     }
 };
@@ -88,7 +97,12 @@ maxpool_fwd_kernel(Mri3dPoolGeom g, const T* __restrict__ x, T* __restrict__ y, 
             const int64_t ov = obase + pix;
             o.store(y + ov * g.y_ld + cv * VEC);
             uint8_t* ip = idx + ov * g.c + cv * VEC;
-            if (VEC == 4) {
+            if constexpr (VEC == 8) {
+                uint2 pk;
+                pk.x = (uint32_t)bi[0] | ((uint32_t)bi[1] << 8) | ((uint32_t)bi[2] << 16) | ((uint32_t)bi[3] << 24);
+                pk.y = (uint32_t)bi[4] | ((uint32_t)bi[5] << 8) | ((uint32_t)bi[6] << 16) | ((uint32_t)bi[7] << 24);
+                *reinterpret_cast<uint2*>(ip) = pk;
+            } else if constexpr (VEC == 4) {
                 *reinterpret_cast<uint32_t*>(ip) = (uint32_t)bi[0] | ((uint32_t)bi[1] << 8) |
                                                    ((uint32_t)bi[VEC > 2 ? 2 : 0] << 16) | ((uint32_t)bi[VEC > 3 ? 3 : 0] << 24);
             } else {
@@ -144,7 +158,14 @@ maxpool_bwd_kernel(Mri3dPoolGeom g, const T* __restrict__ dy, const uint8_t* __r
                         V<VEC> gv;
                         gv.load(dy + ov * g.y_ld + cv * VEC);
                         const uint8_t* ip = idx + ov * g.c + cv * VEC;
-                        if (VEC == 4) {
+                        if constexpr (VEC == 8) {
+                            const uint2 pk = *reinterpret_cast<const uint2*>(ip);
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) {
+                                if ((int)((pk.x >> (8 * j)) & 0xff) == tap) acc[j] += gv.v[j];
+                                if ((int)((pk.y >> (8 * j)) & 0xff) == tap) acc[4 + j] += gv.v[4 + j];
+                            }
+                        } else if constexpr (VEC == 4) {
                             const uint32_t pk = *reinterpret_cast<const uint32_t*>(ip);
 #pragma unroll
                             for (int j = 0; j < VEC; ++j)
@@ -679,9 +700,15 @@ extern "C" int mri3d_maxpool3d_fwd(const Mri3dPoolGeom* g, const void* x, void* 
     hipStream_t s = static_cast<hipStream_t>(stream);
     bool v4 = vec_ok(g->dtype, g->c, g->x_ld, g->y_ld, x, y) && (reinterpret_cast<uintptr_t>(idx) & 3) == 0;
     int hch, grid;
-    slab_plan(g->n * g->dout, g->ho, g->wo, g->c / (v4 ? 4 : 1), hch, grid);
+    const bool v8 = v4 && g->dtype == MRI3D_BF16 && g->c % 8 == 0 && g->x_ld % 8 == 0 && g->y_ld % 8 == 0 && aligned16(x, y) &&
+                    (reinterpret_cast<uintptr_t>(idx) & 7) == 0;
+    slab_plan(g->n * g->dout, g->ho, g->wo, g->c / (v8 ? 8 : (v4 ? 4 : 1)), hch, grid);
     MRI3D_DISPATCH_DTYPE(g->dtype, T, {
-        if (v4)
+        if constexpr (sizeof(T) == 2) {
+            if (v8) hipLaunchKernelGGL((maxpool_fwd_kernel<T, 8>), dim3(grid), dim3(256), 0, s, *g, (const T*)x, (T*)y, idx, hch);
+        }
+        if (v8) {
+        } else if (v4)
             hipLaunchKernelGGL((maxpool_fwd_kernel<T, 4>), dim3(grid), dim3(256), 0, s, *g, (const T*)x, (T*)y, idx, hch);
         else
             hipLaunchKernelGGL((maxpool_fwd_kernel<T, 1>), dim3(grid), dim3(256), 0, s, *g, (const T*)x, (T*)y, idx, hch);
@@ -699,9 +726,16 @@ static int maxpool_bwd_impl(const Mri3dPoolGeom* g, const void* dy, const uint8_
     bool v4 = vec_ok(g->dtype, g->c, g->x_ld, g->y_ld, dx, dy) && (reinterpret_cast<uintptr_t>(idx) & 3) == 0 &&
               (addend == nullptr || (a_ld % 4 == 0 && aligned_vec4(g->dtype, addend)));
     int hch, grid;
-    slab_plan(g->n * g->di, g->hi, g->wi, g->c / (v4 ? 4 : 1), hch, grid);
+    const bool v8 = v4 && g->dtype == MRI3D_BF16 && g->c % 8 == 0 && g->x_ld % 8 == 0 && g->y_ld % 8 == 0 && aligned16(dx, dy) &&
+                    (reinterpret_cast<uintptr_t>(idx) & 7) == 0 && (addend == nullptr || (a_ld % 8 == 0 && aligned16(addend)));
+    slab_plan(g->n * g->di, g->hi, g->wi, g->c / (v8 ? 8 : (v4 ? 4 : 1)), hch, grid);
     MRI3D_DISPATCH_DTYPE(g->dtype, T, {
-        if (v4)
+        if constexpr (sizeof(T) == 2) {
+            if (v8) hipLaunchKernelGGL((maxpool_bwd_kernel<T, 8>), dim3(grid), dim3(256), 0, s, *g, (const T*)dy, idx, (T*)dx, hch,
+                                       (const T*)addend, a_ld);
+        }
+        if (v8) {
+        } else if (v4)
             hipLaunchKernelGGL((maxpool_bwd_kernel<T, 4>), dim3(grid), dim3(256), 0, s, *g, (const T*)dy, idx, (T*)dx, hch,
                                (const T*)addend, a_ld);
         else

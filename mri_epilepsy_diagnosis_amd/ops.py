@@ -343,7 +343,16 @@ class GradSink:
     """Where a parameter's gradient lives when `parallel.FlatParams` owns it: a view into the flat gradient buffer.  The
     backward of every op here writes a parameter gradient STRAIGHT into that view the first time the parameter is used after
     `FlatParams.zero_grad()` (later uses add to it) and hands autograd `None`, so there is no AccumulateGrad `add_` kernel per
-    parameter per step (59 of them in the c0=8 U-Net)."""
+    parameter per step (59 of them in the c0=8 U-Net).
+
+    Contract (what a caller of an attached model can rely on):
+      * `loss.backward()` behaves as usual: afterwards `p.grad` holds the accumulated gradient.
+      * Zero gradients with `FlatParams.zero_grad()` (or the engine's step objects).  `flat.grad.zero_()` / `p.grad.zero_()` are
+        also correct — the sink then ADDS into the zeroed view instead of overwriting it — just one `add_` slower.
+      * The sink cannot tell `backward()` from `torch.autograd.grad(loss, params)` or `backward(inputs=[...])`: under those it
+        would still write into `p.grad` and hand autograd None.  Code that wants gradient TENSORS of attached parameters
+        (gradient penalties, inspection) wraps that call in `with ops.suspend_grad_sinks():` — the ops then return their
+        parameter gradients to autograd like any other function."""
 
     __slots__ = ("view", "fresh")
 
@@ -351,8 +360,27 @@ class GradSink:
         self.view, self.fresh = view, True
 
 
+_sinks_suspended = 0
+
+
+class suspend_grad_sinks:
+    """Context manager: inside it every op returns its parameter gradients to autograd (see GradSink's contract)."""
+
+    def __enter__(self):
+        global _sinks_suspended
+        _sinks_suspended += 1
+        return self
+
+    def __exit__(self, *exc):
+        global _sinks_suspended
+        _sinks_suspended -= 1
+        return False
+
+
 def _live_sink(param):
     """param's sink if it is still what param.grad points at (a caller may have dropped or replaced .grad), else None."""
+    if _sinks_suspended:
+        return None
     sink = getattr(param, "_mri3d_grad_sink", None) if param is not None else None
     if sink is None or param.grad is None or param.grad.data_ptr() != sink.view.data_ptr() or sink.view.shape != param.shape:
         return None
@@ -615,15 +643,22 @@ class _NormActFn(torch.autograd.Function):
             with _timed(lambda: "norm_stats c%d vox%d n%d" % (c, g.vox, n), lambda: {"flops": 0.0, "bytes": _esz(x) * x.numel()}):
                 check(L.mri3d_norm_stats(ctypes.byref(g), _ptr(x), _ptr(mean_l), _ptr(invstd_l), None, None, float(momentum),
                                          _ptr(ws), ws.numel(), _stream()), "norm_stats")
+            # Wire format: (count, sum(x - s), sum((x - s)^2)) per channel in float64, with the shift s = running_mean (the same on
+            # every rank: the buffers start equal and are only ever updated by this code with the reduced statistics) or 0
+            # without running statistics.  The local variance comes from the statistics kernel's own shifted float64 sums, so
+            # nothing here subtracts two large numbers once s has followed the mean (|mean| >> std: a raw E[x^2] - mean^2
+            # across ranks would lose mean^2/var digits).
             cnt_l = float(n * g.vox)
-            m64 = mean_l.double()
+            shift = running_mean.detach().double() if running_mean is not None else torch.zeros(c, dtype=torch.float64, device=x.device)
+            m64 = mean_l.double() - shift
             var_l = (1.0 / invstd_l.double() ** 2 - float(eps)).clamp_(min=0.0)
             pack = torch.cat([torch.full((1,), cnt_l, dtype=torch.float64, device=x.device), cnt_l * m64,
                               cnt_l * (var_l + m64 * m64)])
             pack = reducer.all_reduce(pack)
             cnt = pack[0]
-            gmean = pack[1:1 + c] / cnt
-            gvar = (pack[1 + c:] / cnt - gmean * gmean).clamp_(min=0.0)
+            gm_s = pack[1:1 + c] / cnt
+            gmean = gm_s + shift
+            gvar = (pack[1 + c:] / cnt - gm_s * gm_s).clamp_(min=0.0)
             mean = gmean.to(torch.float32).contiguous()
             invstd = torch.rsqrt(gvar + float(eps)).to(torch.float32).contiguous()
             if running_mean is not None:

@@ -18,7 +18,11 @@ from . import _lib, ops
 
 
 class FlatParams:
-    """Flatten a module's trainable parameters and gradients into two contiguous buffers (views stay live)."""
+    """Flatten a module's trainable parameters and gradients into two contiguous buffers (views stay live).
+
+    While attached, the HIP ops write parameter gradients straight into `self.grad` (ops.GradSink — its docstring states the
+    contract: zero through `zero_grad()`; wrap `torch.autograd.grad(...)` / `backward(inputs=...)` over attached parameters in
+    `with ops.suspend_grad_sinks():`)."""
 
     def __init__(self, module):
         seen, params = set(), []

@@ -450,6 +450,28 @@ def test_flat_params_gradient_sinks_match_plain_autograd():
             assert torch.equal(pa.grad, pb.grad), name
 
 
+def test_autograd_grad_over_attached_parameters_with_suspended_sinks():
+    """GradSink contract: with FlatParams attached, `torch.autograd.grad` inside `ops.suspend_grad_sinks()` returns the gradient
+    tensors and leaves `.grad` alone; outside it, backward() fills `.grad` with the same numbers."""
+    from mri_epilepsy_diagnosis_amd import nn as mnn
+    torch.manual_seed(2)
+    m = torch.nn.Sequential(mnn.Conv3d(4, 8, 3, padding=1), mnn.BatchNorm3d(8), mnn.ReLU(), mnn.Conv3d(8, 2, 1)).cuda()
+    flat = parallel.FlatParams(m)
+    x = torch.randn(2, 4, 6, 7, 9, device="cuda")
+    flat.zero_grad()
+    m(x).square().mean().backward()
+    want = [p.grad.detach().clone() for p in m.parameters()]
+    flat.zero_grad()
+    with ops.suspend_grad_sinks():
+        got = torch.autograd.grad(m(x).square().mean(), list(m.parameters()))
+    assert all(g is not None for g in got)
+    assert all(torch.allclose(g, w, rtol=1e-5, atol=1e-7) for g, w in zip(got, want))
+    assert float(flat.grad.abs().max()) == 0.0          # untouched
+    flat.zero_grad()
+    m(x).square().mean().backward()                      # and the sinks are live again afterwards
+    assert all(torch.allclose(p.grad, w, rtol=1e-5, atol=1e-7) for p, w in zip(m.parameters(), want))
+
+
 class _OtherRank:
     """Stands in for the second data-parallel rank of a synchronised BatchNorm: adds that rank's contribution (computed
     analytically by the test) to each collective, in call order."""
@@ -461,6 +483,37 @@ class _OtherRank:
         out = t + self.contributions[self.calls].to(t)
         self.calls += 1
         return out
+
+
+@pytest.mark.parametrize("warm", [False, True], ids=["cold_running_mean", "warm_running_mean"])
+def test_sync_batchnorm_keeps_its_digits_when_the_mean_dwarfs_the_spread(warm):
+    """Channels with |mean| = 100 x std (un-normalised intensities), the two ranks' local means apart by a fraction of a std: the
+    merged variance must agree with the float64 variance of the pooled batch to 1e-5 relative — with the shift at 0 (first step)
+    and at the running mean (every later step).  The wire format is (count, sum(x - s), sum((x - s)^2)), s = running_mean."""
+    torch.manual_seed(11)
+    c, shape = 8, (6, 10, 12)
+    x = torch.randn(4, c, *shape) * 0.05 + 5.0
+    x[2:] += 0.02                                   # the other rank sees a slightly different population
+    s0 = torch.full((c,), 5.0) if warm else torch.zeros(c)
+    xb = x[2:].double()
+    red = (0, 2, 3, 4)
+    sh = s0.double().view(1, c, 1, 1, 1)
+    fwd_b = torch.cat([torch.tensor([float(xb.numel() // c)], dtype=torch.float64), (xb - sh).sum(red), ((xb - sh) ** 2).sum(red)])
+    reducer = _OtherRank([fwd_b])
+    xd = x[:2].cuda().contiguous(memory_format=torch.channels_last_3d)
+    rm, rv = s0.clone().cuda(), torch.ones(c, device="cuda")
+    gamma, beta = torch.ones(c, device="cuda"), torch.zeros(c, device="cuda")
+    prev = ops.set_sync_batchnorm(reducer)
+    try:
+        with torch.no_grad():
+            y = ops.norm_act(xd, gamma, beta, None, rm, rv, "sync", 1.0, 0.0, None)   # momentum 1: running = this batch's
+    finally:
+        ops.set_sync_batchnorm(prev)
+    mean64, var64 = x.double().mean(red), x.double().var(red, unbiased=True)
+    assert torch.allclose(rm.cpu().double(), mean64, rtol=2e-7, atol=0)
+    assert torch.allclose(rv.cpu().double(), var64, rtol=1e-5, atol=0), ((rv.cpu().double() - var64) / var64).abs().max()
+    want = ((x[:2].double() - mean64.view(1, c, 1, 1, 1)) / x.double().var(red, unbiased=False).sqrt().view(1, c, 1, 1, 1))
+    assert torch.allclose(y.cpu().double(), want, rtol=0, atol=2e-4)   # x itself is fp32: (x - mean)/std carries 100 x eps_fp32
 
 
 @pytest.mark.parametrize("act", [None, "relu"])
