@@ -572,9 +572,6 @@ extern "C" int mri3d_norm_stats(const Mri3dNormGeom* g, const void* x, float* me
     const int tot = p.groups * g->c;
     MRI3D_DISPATCH_DTYPE(g->dtype, T, {
         const T* xf = static_cast<const T*>(x);
-        if constexpr (sizeof(T) == 2) {
-            if (p.vec == 8) hipLaunchKernelGGL((norm_stats_kernel<T, 8>), grid, dim3(256), 0, s, xf, part, g->c, g->x_ld, p.gvox, p.CL, p.VT);
-        }
         if (p.vec == 4)
             hipLaunchKernelGGL((norm_stats_kernel<T, 4>), grid, dim3(256), 0, s, xf, part, g->c, g->x_ld, p.gvox, p.CL, p.VT);
         else if (p.vec == 1)
@@ -658,11 +655,6 @@ extern "C" int mri3d_norm_act_bwd(const Mri3dNormGeom* g, int training, const vo
         const T* df = static_cast<const T*>(dy);
         T* of = static_cast<T*>(dx);
         if (need_reduce) {
-            if constexpr (sizeof(T) == 2) {
-                if (p.vec == 8) hipLaunchKernelGGL((norm_act_bwd_reduce_kernel<T, 8>), grid, dim3(256), 0, s, xf, df, part, mean, invstd,
-                                   gamma, beta, alpha, g->alpha_n, g->act, g->slope, g->c, g->x_ld, g->y_ld, p.gvox, p.CL,
-                                   p.VT);
-            }
             if (p.vec == 4)
                 hipLaunchKernelGGL((norm_act_bwd_reduce_kernel<T, 4>), grid, dim3(256), 0, s, xf, df, part, mean, invstd,
                                    gamma, beta, alpha, g->alpha_n, g->act, g->slope, g->c, g->x_ld, g->y_ld, p.gvox, p.CL,
@@ -681,11 +673,6 @@ extern "C" int mri3d_norm_act_bwd(const Mri3dNormGeom* g, int training, const vo
                 hipLaunchKernelGGL(norm_act_bwd_group_combine_kernel, dim3(cdiv(ng, 64)), dim3(64), 0, s, sums, gamma,
                                    g->c, p.groups, g->group_c);
             }
-        }
-        if constexpr (sizeof(T) == 2) {
-            if (p.vec == 8) hipLaunchKernelGGL((norm_act_bwd_apply_kernel<T, 8>), grid, dim3(256), 0, s, xf, df, of, sums, mean, invstd,
-                               gamma, beta, alpha, g->alpha_n, g->act, g->slope, training, g->c, g->x_ld, g->y_ld, p.gvox,
-                               p.CL, p.VT, g->group_c);
         }
         if (p.vec == 4)
             hipLaunchKernelGGL((norm_act_bwd_apply_kernel<T, 4>), grid, dim3(256), 0, s, xf, df, of, sums, mean, invstd,
