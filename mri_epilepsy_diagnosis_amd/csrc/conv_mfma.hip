@@ -534,90 +534,193 @@ conv_mfma_fwd2_kernel(const T* __restrict__ x, const float* __restrict__ wp, con
     }
 }
 
-// ------------------------------------------------------------------ forward / dgrad for SMALL volumes (fp32)
-// The tiled kernel above needs thousands of 4x8x16 tiles to fill 512 workgroup slots; the deep levels of Modified3DUNet
-// (modified_3dunet.py:33-70: 64 -> 64 at 20x24x20, 128 -> 128 at 10x12x10, batch 1) have 6 .. 60 of them and ran at 5 .. 10 TFLOP/s,
-// with half-empty tiles on top (W = 10 or 20 against a tile width of 16).  Here a WAVE is the unit: 16 consecutive voxels of the
-// flattened (n, d, h, w) index space x NT N-tiles, the whole K = 27 taps x Cin in one go, operands straight from global memory
-// (the whole input of such a layer is < 1 MB: L2-resident) — no LDS, no barriers, no tile waste.  A lane's voxel coordinates
-// are computed once; a tap is a constant element offset plus three range checks.  Same operand order, K permutation and
-// epilogue as the tiled kernel; packed weights Wp[chunk16][tap][nt][lane][s] (pack_w_mfma_kernel, CK = 16).
-template <int NT>
+// ------------------------------------------------------------------ forward / dgrad without LDS: small volumes and strided layers
+// The tiled kernel above needs thousands of 4x8x16 tiles to fill 512 workgroup slots and a stride of 1; the deep levels of
+// Modified3DUNet (modified_3dunet.py:23-70: 64 -> 64 at 20x24x20, 128 -> 128 at 10x12x10, batch 1, and the four stride-2
+// 3x3x3 layers between the levels), VoxResNet's stride-2 stem (cnn_model.py:49-81) and patch batches have neither, and ran on
+// the direct (non-MFMA) kernels at 2 .. 13 TFLOP/s.  Here a WAVE is the unit: one M-tile of 16 voxels x NT N-tiles of 16 channels,
+// the whole K = taps x Cin in one go, both operands straight from global memory (L2-resident at these sizes) — no LDS staging,
+// no barriers, no tile waste.  Same operand order (weights, voxels), K permutation and epilogue as the tiled kernel; packed
+// weights Wp[chunk16][tap][nt][lane][s] (pack_w_mfma_kernel, CK = 16).
+//   MODE 0 (forward of a 3x3x3 / pad 1 / stride s layer; also the stride-1 data gradient = the forward of the flipped,
+//           transposed weights on dY): the M-tile is 16 consecutive voxels of the flattened (n, od, oh, ow) OUTPUT index space;
+//           tap (kd, kh, kw) reads input voxel (s*od - 1 + kd, ...), a constant element offset plus three range checks.
+//   MODE 1 (data gradient of a stride-s layer, s > 1): dX[i] = sum over the taps with k = (i + 1) mod s of W[k] dY[(i + 1 - k)/s].
+//           The M-tile is 16 input voxels of one (n, id, ih) row that share the residue of iw mod s, so the valid tap set —
+//           1 .. 8 of the 27 — is wave-uniform: the tap loops just step by s and only the volume border is masked.
+//   SPLIT: layers with fewer units than SIMDs give each unit to a whole workgroup: its four waves take the (kd, kh) pairs
+//           round-robin and are summed through LDS in a fixed order (deterministic); otherwise a workgroup is four units.
+// The loads of all kw taps of a (kd, kh) pair — up to 3 voxel fragments and 3 NT weight fragments per 16-channel chunk — are
+// issued together before their MFMAs: a lone wave per SIMD then waits for L2 once per pair instead of once per MFMA group.
+struct DirectGeom {
+    int N, Di, Hi, Wi;   // the tensor the kernel READS (x, or dY for the gradients)
+    int Do, Ho, Wo;      // the tensor it WRITES
+    int s, Kc, in_ld, Nc, out_ld, NTT, gy, nmt, wbn;
+};
+
+template <typename T, int NT, int MODE, bool SPLIT>
 __global__ void __launch_bounds__(256)
-conv_mfma_small_kernel(const float* __restrict__ x, const float* __restrict__ wp, const float* __restrict__ bias,
-                       float* __restrict__ y, int N, int D, int H, int W, int Kc, int x_ld, int Nc, int y_ld, int NTT, int gy,
-                       int nmt) {
-    const int lane = threadIdx.x & 63, li = lane & 15, kq = lane >> 4;
-    const int unit = blockIdx.x * 4 + (threadIdx.x >> 6);          // (M-tile, N-block), N-block fastest: the waves of a
-    if (unit >= nmt * gy) return;                                  // workgroup share their voxel fragments through L1
-    const int ntb = unit % gy, mt = unit / gy;
-    const int64_t nvox = (int64_t)N * D * H * W;
-    const int64_t v = (int64_t)mt * 16 + li;
-    const bool vok = v < nvox;
-    const int64_t vc = vok ? v : nvox - 1;
-    const int w0 = (int)(vc % W);
-    int64_t t = vc / W;
-    const int h0 = (int)(t % H);
-    t /= H;
-    const int d0 = (int)(t % D);
-    const float* x0 = x + vc * x_ld;                               // this lane's voxel: always a readable 16 bytes (Kc >= 8)
-    const float* xv = x0 + 4 * kq;                                 // ... its k-group's first channel (may lie past Kc: see cok)
-    const int nchunks = (Kc + 15) / 16;
+conv_mfma_direct_kernel(const T* __restrict__ in, const float* __restrict__ wp, const float* __restrict__ bias,
+                        T* __restrict__ out, const DirectGeom q) {
+    __shared__ float red[SPLIT ? 3 * NT * 256 : 1];
+    const int lane = threadIdx.x & 63, li = lane & 15, kq = lane >> 4, wv = threadIdx.x >> 6;
+    const int unit = SPLIT ? (int)blockIdx.x : (int)blockIdx.x * 4 + wv;
+    if (unit >= q.nmt * q.gy) return;   // SPLIT: whole workgroup; otherwise the wave (no barrier follows)
+    const int ntb = unit % q.gy, mt = unit / q.gy;
+    const int s = q.s;
+
+    // the lane's voxel: where it writes, and the read-side coordinates of its taps
+    bool vok;
+    int64_t out_off;           // element offset of the lane's output voxel
+    int n, c_d, c_h, c_w;      // MODE 0: input coordinates of tap (0,0,0); MODE 1: the input-gradient voxel (id, ih, iw)
+    if (MODE == 0) {
+        const int64_t nvox = (int64_t)q.N * q.Do * q.Ho * q.Wo;
+        const int64_t v = (int64_t)mt * 16 + li;
+        vok = v < nvox;
+        const int64_t vc = vok ? v : nvox - 1;
+        const int ow = (int)(vc % q.Wo);
+        int64_t t = vc / q.Wo;
+        const int oh = (int)(t % q.Ho);
+        t /= q.Ho;
+        const int od = (int)(t % q.Do);
+        n = (int)(t / q.Do);
+        c_d = od * s - 1, c_h = oh * s - 1, c_w = ow * s - 1;
+        out_off = vc * q.out_ld;
+    } else {
+        int r = mt / q.wbn;
+        const int wb = mt % q.wbn;
+        const int rw = r % s;
+        r /= s;
+        c_h = r % q.Ho;
+        r /= q.Ho;
+        c_d = r % q.Do;
+        n = r / q.Do;
+        c_w = rw + s * (wb * 16 + li);
+        vok = c_w < q.Wo;
+        out_off = ((((int64_t)n * q.Do + c_d) * q.Ho + c_h) * q.Wo + (vok ? c_w : 0)) * q.out_ld;
+    }
+    const T* const in_n = in + (int64_t)n * q.Di * q.Hi * q.Wi * q.in_ld;   // sample base: always readable (Kc >= 8)
+    const int nchunks = (q.Kc + 15) / 16;
     const int nt0 = ntb * NT;
+    const float* const wbase = wp + (size_t)nt0 * 256 + lane * 4;
+    const size_t wtap = (size_t)q.NTT * 256, wchunk = (size_t)27 * q.NTT * 256;
 
     f32x4 acc[NT];
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) acc[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
-    const float* wbase = wp + (size_t)nt0 * 256 + lane * 4;
-    const size_t wtap = (size_t)NTT * 256, wchunk = (size_t)27 * NTT * 256;
 
+    // (kd, kh) pairs of this wave; MODE 1 starts at the residue tap and steps by the stride
+    const int kd0 = MODE == 0 ? 0 : (c_d + 1) % s, kh0 = MODE == 0 ? 0 : (c_h + 1) % s, kstep = MODE == 0 ? 1 : s;
+    int pair = 0;
 #pragma unroll 1
-    for (int kd = 0; kd < 3; ++kd) {
-        const bool okd = vok && (unsigned)(d0 + kd - 1) < (unsigned)D;
+    for (int kd = kd0; kd < 3; kd += kstep) {
+        int rd;   // read-side d coordinate
+        if (MODE == 0) rd = c_d + kd;
+        else {
+            const int nd = c_d + 1 - kd;
+            rd = nd >= 0 ? nd / s : -1;
+        }
+        const bool okd = (unsigned)rd < (unsigned)q.Di;   // MODE 1: wave-uniform
 #pragma unroll 1
-        for (int kh = 0; kh < 3; ++kh) {
-            const bool okh = okd && (unsigned)(h0 + kh - 1) < (unsigned)H;
+        for (int kh = kh0; kh < 3; kh += kstep, ++pair) {
+            if (SPLIT && (pair & 3) != wv) continue;
+            int rh;
+            if (MODE == 0) rh = c_h + kh;
+            else {
+                const int nh = c_h + 1 - kh;
+                rh = nh >= 0 ? nh / s : -1;
+            }
+            const bool okh = okd && (unsigned)rh < (unsigned)q.Hi;
+            if (MODE == 1 && !okh) continue;   // wave-uniform in MODE 1
+            // the kw taps of this pair: source pointer (clamped to the sample base when masked), mask, weight tap
+            const T* src[3];
+            bool okw[3];
+            int wtapi[3];
+            int nkw = 0;
 #pragma unroll
-            for (int kw = 0; kw < 3; ++kw) {
-                const bool ok = okh && (unsigned)(w0 + kw - 1) < (unsigned)W;
-                const int tap = (kd * 3 + kh) * 3 + kw;
-                const int64_t eoff = ((int64_t)((kd - 1) * H + (kh - 1)) * W + (kw - 1)) * x_ld;
-                const float* src = ok ? xv + eoff : x0;            // clamped address, zeroed below
-                const float* wt = wbase + (size_t)tap * wtap;
-                for (int ch = 0; ch < nchunks; ++ch) {
-                    const bool cok = ok && ch * 16 + 4 * kq < Kc;   // Kc % 4 == 0 (host)
-                    float4 a = *reinterpret_cast<const float4*>(cok ? src + ch * 16 : x0);
-                    if (!cok) a = make_float4(0.f, 0.f, 0.f, 0.f);
-                    const float av[4] = {a.x, a.y, a.z, a.w};
+            for (int j = 0; j < 3; ++j) {
+                int kw, rwc;
+                bool have;
+                if (MODE == 0) {
+                    kw = j;
+                    have = true;
+                    rwc = c_w + kw;
+                } else {
+                    kw = (c_w + 1) % s + j * s;   // wave-uniform: c_w mod s is the M-tile's residue
+                    have = kw < 3;
+                    const int nw = c_w + 1 - kw;
+                    rwc = nw >= 0 ? nw / s : -1;
+                }
+                const bool ok = have && vok && okh && (unsigned)rwc < (unsigned)q.Wi;
+                okw[j] = ok;
+                src[j] = ok ? in_n + (((int64_t)rd * q.Hi + rh) * q.Wi + rwc) * q.in_ld : in_n;
+                const int tap = (kd * 3 + kh) * 3 + (have ? kw : 0);
+                wtapi[j] = MODE == 0 ? tap : 26 - tap;   // MODE 1 reads the gradient image (pack_w_mfma_kernel dgrad = 1: 26 - tap)
+                if (have) nkw = j + 1;
+            }
+#pragma unroll 1
+            for (int ch = 0; ch < nchunks; ++ch) {
+                const bool cok = ch * 16 + 4 * kq < q.Kc;   // Kc % 4 == 0 (host)
+                float4 a[3];
+                f32x4 b[3][NT];
 #pragma unroll
-                    for (int nt = 0; nt < NT; ++nt) {
-                        const f32x4 b = *reinterpret_cast<const f32x4*>(wt + (size_t)ch * wchunk + nt * 256);
+                for (int j = 0; j < 3; ++j) {
+                    if (j < nkw) {
+                        a[j] = ldf4((okw[j] && cok) ? src[j] + ch * 16 + 4 * kq : in_n);
+                        if (!(okw[j] && cok)) a[j] = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-                        for (int s4 = 0; s4 < 4; ++s4)
-                            acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(b[s4], av[s4], acc[nt], 0, 0, 0);
+                        for (int nt = 0; nt < NT; ++nt)
+                            b[j][nt] = *reinterpret_cast<const f32x4*>(wbase + (size_t)wtapi[j] * wtap + (size_t)ch * wchunk + nt * 256);
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j < 3; ++j) {
+                    if (j < nkw) {
+                        const float av[4] = {a[j].x, a[j].y, a[j].z, a[j].w};
+#pragma unroll
+                        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                            for (int s4 = 0; s4 < 4; ++s4)
+                                acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(b[j][nt][s4], av[s4], acc[nt], 0, 0, 0);
                     }
                 }
             }
         }
     }
+    if (SPLIT) {   // waves 1..3 -> LDS, wave 0 adds them in a fixed order
+        if (wv > 0) {
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) red[((wv - 1) * NT + nt) * 256 + r * 64 + lane] = acc[nt][r];
+        }
+        __syncthreads();
+        if (wv > 0) return;
+#pragma unroll
+        for (int w = 0; w < 3; ++w)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[nt][r] += red[(w * NT + nt) * 256 + r * 64 + lane];
+    }
     if (!vok) return;
-    float* yv = y + v * y_ld;
+    T* yv = out + out_off;
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
         const int co = (nt0 + nt) * 16 + 4 * kq;
-        if (co >= Nc) continue;
+        if (co >= q.Nc) continue;
         float bv[4] = {0.f, 0.f, 0.f, 0.f};
         if (bias) {
 #pragma unroll
             for (int r = 0; r < 4; ++r)
-                if (co + r < Nc) bv[r] = bias[co + r];
+                if (co + r < q.Nc) bv[r] = bias[co + r];
         }
-        if (co + 3 < Nc && (y_ld & 3) == 0) {
+        if (co + 3 < q.Nc && (q.out_ld & 3) == 0) {
             stf4(yv + co, make_float4(acc[nt][0] + bv[0], acc[nt][1] + bv[1], acc[nt][2] + bv[2], acc[nt][3] + bv[3]));
         } else {
 #pragma unroll
             for (int r = 0; r < 4; ++r)
-                if (co + r < Nc) yv[co + r] = acc[nt][r] + bv[r];
+                if (co + r < q.Nc) stf(yv + co + r, acc[nt][r] + bv[r]);
         }
     }
 }
@@ -625,9 +728,75 @@ conv_mfma_small_kernel(const float* __restrict__ x, const float* __restrict__ wp
 // ------------------------------------------------------------------ host side
 struct MfmaFwdPlan {
     int CK, NT, NTT, gy, nchunks, tilesD, tilesH, tilesW, ntiles, grid;
-    int small, s_nt, s_gy, s_nmt;   // small-volume kernel (fp32): N-tiles per wave, N-blocks, 16-voxel M-tiles
+    int small;   // served by the LDS-free kernel (conv_mfma_direct_kernel) when there are fewer tiles than workgroup slots
     size_t wp_floats, s_wp_floats, smem, stat_smem;   // packed-weight image of the tiled / the small-volume kernel
 };
+
+// Plan of the LDS-free kernel (conv_mfma_direct_kernel): 3x3x3, pad 1, dilation 1, one stride s for the three axes.
+struct DirectPlan {
+    DirectGeom q;
+    int nt, mode, split, units;
+    size_t wp_floats;
+};
+
+static bool direct_plan(const Mri3dConvGeom& g, bool dgrad, DirectPlan& p) {
+    if (!(g.kd == 3 && g.kh == 3 && g.kw == 3 && g.pd == 1 && g.ph == 1 && g.pw == 1 && g.dd == 1 && g.dh == 1 && g.dw == 1 &&
+          g.sd == g.sh && g.sh == g.sw && g.sd >= 1 && g.sd <= 3))
+        return false;
+    const int Kc = dgrad ? g.co : g.ci, Nc = dgrad ? g.ci : g.co;
+    const int in_ld = dgrad ? g.y_ld : g.x_ld, out_ld = dgrad ? g.x_ld : g.y_ld;
+    if (Kc % 4 != 0 || Kc < 8 || in_ld % 4 != 0 || Nc < 8) return false;   // 4-channel fragments; tiny outputs stay on the gather kernels
+    DirectGeom& q = p.q;
+    q.N = g.n;
+    q.s = g.sd;
+    p.mode = (dgrad && g.sd > 1) ? 1 : 0;
+    if (!dgrad) {            // reads x (di..), writes y (dout..)
+        q.Di = g.di, q.Hi = g.hi, q.Wi = g.wi, q.Do = g.dout, q.Ho = g.ho, q.Wo = g.wo;
+    } else if (p.mode == 1) {   // reads dY (dout..), writes dX (di..)
+        q.Di = g.dout, q.Hi = g.ho, q.Wi = g.wo, q.Do = g.di, q.Ho = g.hi, q.Wo = g.wi;
+    } else {                 // stride 1: the gradient is the forward of the flipped weights on dY, same extents
+        q.Di = g.dout, q.Hi = g.ho, q.Wi = g.wo, q.Do = g.di, q.Ho = g.hi, q.Wo = g.wi;
+    }
+    q.Kc = Kc, q.in_ld = in_ld, q.Nc = Nc, q.out_ld = out_ld;
+    q.NTT = cdiv(Nc, 16);
+    const int64_t nvox_out = (int64_t)q.N * q.Do * q.Ho * q.Wo;
+    int64_t nmt;
+    if (p.mode == 0) {
+        q.wbn = 1;
+        nmt = (nvox_out + 15) / 16;
+    } else {
+        q.wbn = cdiv(cdiv(q.Wo, q.s), 16);
+        nmt = (int64_t)q.N * q.Do * q.Ho * q.s * q.wbn;
+    }
+    if (nmt * q.NTT > 0x3fffffff || nvox_out > 0x7fffffff || (int64_t)q.N * q.Di * q.Hi * q.Wi > 0x7fffffff) return false;
+    q.nmt = (int)nmt;
+    // enough waves for ~4 per SIMD where the layer allows it: narrower N-blocks when there are few M-tiles
+    p.nt = (q.NTT % 4 == 0) ? 4 : ((q.NTT % 2 == 0) ? 2 : 1);
+    while (p.nt > 1 && nmt * (q.NTT / p.nt) < 4096) p.nt >>= 1;
+    q.gy = q.NTT / p.nt;
+    p.units = q.nmt * q.gy;
+    p.split = p.units < 1024 ? 1 : 0;   // fewer units than SIMDs: a workgroup per unit, its waves split the taps
+    p.wp_floats = (size_t)cdiv(Kc, 16) * 27 * q.NTT * 256;   // [chunk16][tap][nt][lane][s]
+    return true;
+}
+
+template <typename T>
+static void launch_direct(const DirectPlan& p, const T* in, const float* wp, const float* bias, T* out, hipStream_t s) {
+    const int grid = p.split ? p.units : cdiv(p.units, 4);
+#define MRI3D_DIRECT_CASE(NTv, MODEv, SPv)                                                                            \
+    if (p.nt == NTv && p.mode == MODEv && p.split == SPv)                                                             \
+        hipLaunchKernelGGL((conv_mfma_direct_kernel<T, NTv, MODEv, (SPv != 0)>), dim3(grid), dim3(256), 0, s, in, wp, bias, out, p.q);
+#define MRI3D_DIRECT_NT(MODEv, SPv) MRI3D_DIRECT_CASE(1, MODEv, SPv) MRI3D_DIRECT_CASE(2, MODEv, SPv) MRI3D_DIRECT_CASE(4, MODEv, SPv)
+    MRI3D_DIRECT_NT(0, 0)
+    MRI3D_DIRECT_NT(0, 1)
+    MRI3D_DIRECT_NT(1, 0)
+    MRI3D_DIRECT_NT(1, 1)
+#undef MRI3D_DIRECT_NT
+#undef MRI3D_DIRECT_CASE
+}
+
+// strided layers: served by the LDS-free kernel only
+static bool direct_only(const Mri3dConvGeom& g) { return g.sd > 1 || g.sh > 1 || g.sw > 1; }
 
 static bool mfma_fwd_plan(const Mri3dConvGeom& g, bool dgrad, MfmaFwdPlan& p) {
     if (!(g.kd == 3 && g.kh == 3 && g.kw == 3 && g.sd == 1 && g.sh == 1 && g.sw == 1 && g.pd == 1 && g.ph == 1 &&
@@ -662,14 +831,10 @@ static bool mfma_fwd_plan(const Mri3dConvGeom& g, bool dgrad, MfmaFwdPlan& p) {
     p.small = 0;
     p.s_wp_floats = 0;
     const int64_t nvox = (int64_t)g.n * g.di * g.hi * g.wi;
-    if (!bf && st < 256 && nvox * Kc * 4 <= ((int64_t)32 << 20) && nvox < 0x7fffffff) {
+    DirectPlan dp;
+    if (!bf && st < 256 && nvox * Kc * 4 <= ((int64_t)32 << 20) && direct_plan(g, dgrad, dp)) {   // bf16 tensors stay on the bf16 MFMA
         p.small = 1;
-        p.s_nt = (p.NTT % 4 == 0) ? 4 : ((p.NTT % 2 == 0) ? 2 : 1);
-        p.s_nmt = (int)((nvox + 15) / 16);
-        // enough waves for ~4 per SIMD where the layer allows it: narrower N-blocks when there are few M-tiles
-        while (p.s_nt > 1 && (int64_t)p.s_nmt * (p.NTT / p.s_nt) < 4096) p.s_nt >>= 1;
-        p.s_gy = p.NTT / p.s_nt;
-        p.s_wp_floats = (size_t)cdiv(Kc, 16) * 27 * p.NTT * 256;   // [chunk16][tap][nt][lane][s]
+        p.s_wp_floats = dp.wp_floats;
     }
     return true;
 }
@@ -677,7 +842,16 @@ static bool mfma_fwd_plan(const Mri3dConvGeom& g, bool dgrad, MfmaFwdPlan& p) {
 static int run_mfma_fwd(const Mri3dConvGeom& g, bool dgrad, const void* in_v, const float* w, const float* bias,
                         void* out_v, void* ws, size_t ws_bytes, hipStream_t s, double* stat_part = nullptr) {
     MfmaFwdPlan p;
-    MRI3D_REQUIRE(mfma_fwd_plan(g, dgrad, p), MRI3D_ENOTSUP, "conv3d(mfma): unsupported geometry");
+    DirectPlan dp;
+    const bool strided = direct_only(g);
+    if (strided) {
+        MRI3D_REQUIRE(direct_plan(g, dgrad, dp) && stat_part == nullptr, MRI3D_ENOTSUP, "conv3d(mfma): unsupported strided geometry");
+        p.small = 1;
+        p.wp_floats = 0;
+        p.s_wp_floats = dp.wp_floats;
+    } else {
+        MRI3D_REQUIRE(mfma_fwd_plan(g, dgrad, p), MRI3D_ENOTSUP, "conv3d(mfma): unsupported geometry");
+    }
     const size_t need = std::max(p.wp_floats, p.s_wp_floats) * sizeof(float);
     MRI3D_REQUIRE(ws && ws_bytes >= need, MRI3D_EWORKSPACE, "conv3d(mfma): workspace %zu < %zu", ws_bytes, need);
     MRI3D_REQUIRE(((reinterpret_cast<uintptr_t>(in_v) | reinterpret_cast<uintptr_t>(out_v) | reinterpret_cast<uintptr_t>(ws)) & 15) == 0,
@@ -687,19 +861,12 @@ static int run_mfma_fwd(const Mri3dConvGeom& g, bool dgrad, const void* in_v, co
     const int in_ld = dgrad ? g.y_ld : g.x_ld, out_ld = dgrad ? g.x_ld : g.y_ld;
     int total = (int)p.wp_floats;
     if (p.small && stat_part == nullptr) {
-        const int stotal = (int)p.s_wp_floats;
+        if (!strided) MRI3D_REQUIRE(direct_plan(g, dgrad, dp), MRI3D_ENOTSUP, "conv3d(mfma): unsupported geometry");
+        const int stotal = (int)dp.wp_floats;
         hipLaunchKernelGGL(pack_w_mfma_kernel, dim3(std::min(cdiv(stotal, 256), 2048)), dim3(256), 0, s, w, wp, g.co, g.ci,
-                           dgrad ? 1 : 0, 16, p.NTT, cdiv(Kc, 16));
-        const int units = p.s_nmt * p.s_gy;
-#define MRI3D_SMALL_CASE(NTv)                                                                                         \
-    if (p.s_nt == NTv)                                                                                                \
-        hipLaunchKernelGGL(conv_mfma_small_kernel<NTv>, dim3(cdiv(units, 4)), dim3(256), 0, s, (const float*)in_v, wp, \
-                           bias, (float*)out_v, g.n, g.di, g.hi, g.wi, Kc, in_ld, Nc, out_ld, p.NTT, p.s_gy, p.s_nmt);
-        MRI3D_SMALL_CASE(1)
-        MRI3D_SMALL_CASE(2)
-        MRI3D_SMALL_CASE(4)
-#undef MRI3D_SMALL_CASE
-        return check_launch(dgrad ? "conv3d_dgrad(mfma small)" : "conv3d_fwd(mfma small)");
+                           dgrad ? 1 : 0, 16, dp.q.NTT, cdiv(Kc, 16));
+        MRI3D_DISPATCH_DTYPE(g.dtype, T, { launch_direct<T>(dp, (const T*)in_v, wp, bias, (T*)out_v, s); });
+        return check_launch(dgrad ? "conv3d_dgrad(mfma direct)" : "conv3d_fwd(mfma direct)");
     }
     if (g.dtype == MRI3D_BF16)   // same image size in bytes: 256 floats == 512 bf16 per (chunk, tg, nt)
         hipLaunchKernelGGL(pack_w_mfma_bf16_kernel, dim3(std::min(cdiv(2 * total, 256), 2048)), dim3(256), 0, s, w,
@@ -1807,6 +1974,8 @@ static bool mfma_wgrad_plan(const Mri3dConvGeom& g, MfmaWgradPlan& p) {
 bool conv_mfma_supported(const Mri3dConvGeom& g, int pass) {
     MfmaFwdPlan p;
     MfmaWgradPlan q;
+    DirectPlan dp;
+    if (pass != MRI3D_PASS_WGRAD && direct_only(g)) return direct_plan(g, pass == MRI3D_PASS_DGRAD, dp);
     if (pass == MRI3D_PASS_FWD) return mfma_fwd_plan(g, false, p);
     if (pass == MRI3D_PASS_DGRAD) return mfma_fwd_plan(g, true, p);
     if (pass == MRI3D_PASS_WGRAD) return mfma_wgrad_plan(g, q);
@@ -1816,6 +1985,8 @@ bool conv_mfma_supported(const Mri3dConvGeom& g, int pass) {
 size_t conv_mfma_workspace_bytes(const Mri3dConvGeom& g, int pass) {
     MfmaFwdPlan p;
     MfmaWgradPlan q;
+    DirectPlan dp;
+    if (pass != MRI3D_PASS_WGRAD && direct_only(g)) return direct_plan(g, pass == MRI3D_PASS_DGRAD, dp) ? dp.wp_floats * sizeof(float) : 0;
     if (pass == MRI3D_PASS_FWD && mfma_fwd_plan(g, false, p)) return std::max(p.wp_floats, p.s_wp_floats) * sizeof(float);
     if (pass == MRI3D_PASS_DGRAD && mfma_fwd_plan(g, true, p)) return std::max(p.wp_floats, p.s_wp_floats) * sizeof(float);
     if (pass == MRI3D_PASS_WGRAD && mfma_wgrad_plan(g, q)) return q.part_floats * sizeof(float);

@@ -76,13 +76,33 @@ def test_conv3x3x3_many_small_volumes(case, dtype):
     _run_conv_case(case, dtype)
 
 
-def _run_conv_case(case, dtype):
+# stride-2 3x3x3 layers (modified_3dunet.py:23-38, cnn_model.py:49-81) on the LDS-free MFMA kernel: forward over output M-tiles,
+# data gradient over same-parity input M-tiles with wave-uniform tap sets; even / odd extents (the last output voxel then has no
+# kw = 2 neighbour), pitched slices, few units (a workgroup per unit, taps split over its waves) and many, Kc = 8 (half a chunk)
+STRIDED = [(1, 8, 16, 16, 18, 20, 0, 0, 51), (1, 16, 32, 9, 11, 13, 0, 0, 52), (2, 32, 64, 10, 12, 9, 8, 16, 53),
+           (1, 64, 128, 6, 7, 5, 0, 0, 54), (1, 8, 16, 40, 48, 40, 0, 0, 55), (3, 24, 40, 5, 6, 33, 0, 8, 56),
+           (1, 16, 8, 7, 9, 37, 0, 0, 57), (1, 8, 16, 2, 3, 1, 0, 0, 58)]
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
+@pytest.mark.parametrize("case", STRIDED, ids=lambda c: "n%d_%d-%d_%dx%dx%d_p%d_%d" % c[:8])
+def test_conv3x3x3_stride2(case, dtype):
+    _run_conv_case(case, dtype, stride=2)
+
+
+@pytest.mark.parametrize("case", [(1, 16, 32, 10, 11, 13, 0, 0, 61), (2, 8, 16, 7, 8, 19, 8, 0, 62)], ids=lambda c: "n%d_%d-%d_%dx%dx%d_p%d_%d" % c[:8])
+def test_conv3x3x3_stride3(case):
+    _run_conv_case(case, torch.float32, stride=3)
+
+
+def _run_conv_case(case, dtype, stride=1):
     nb, ci, co, d, h, w, pad_in, pad_out, seed = case
     g = torch.Generator().manual_seed(seed)
     x = torch.randn(nb, ci, d, h, w, generator=g)
     wt = torch.randn(co, ci, 3, 3, 3, generator=g) * (1.0 / np.sqrt(27 * ci))
     b = torch.randn(co, generator=g)
-    dy = torch.randn(nb, co, d, h, w, generator=g)
+    do, ho, wo = [(e - 1) // stride + 1 for e in (d, h, w)]     # k 3, pad 1
+    dy = torch.randn(nb, co, do, ho, wo, generator=g)
     if dtype == torch.bfloat16:
         x, dy = x.to(dtype).float(), dy.to(dtype).float()
     # input as a channel slice of a wider NDHWC buffer (voxel pitch ci + pad_in), as the decoder's concat buffers are
@@ -90,15 +110,15 @@ def _run_conv_case(case, dtype):
     xbuf[:, pad_in:] = x.cuda().to(dtype)
     xg = xbuf[:, pad_in:].detach().requires_grad_(True)
     wg, bg = wt.cuda().requires_grad_(True), b.cuda().requires_grad_(True)
-    yg = ops.conv3d(xg, wg, bg, padding=1)
-    dybuf = torch.zeros(nb, co + pad_out, d, h, w, device="cuda", dtype=dtype).contiguous(memory_format=torch.channels_last_3d)
+    yg = ops.conv3d(xg, wg, bg, stride=stride, padding=1)
+    dybuf = torch.zeros(nb, co + pad_out, do, ho, wo, device="cuda", dtype=dtype).contiguous(memory_format=torch.channels_last_3d)
     dybuf[:, :co] = dy.cuda().to(dtype)
     yg.backward(dybuf[:, :co])
 
     def ref(wref):
         xr = x.clone().requires_grad_(True)
         wr, br = wref.clone().requires_grad_(True), b.clone().requires_grad_(True)
-        yr = F.conv3d(xr, wr, br, padding=1)
+        yr = F.conv3d(xr, wr, br, stride=stride, padding=1)
         yr.backward(dy)
         return yr.detach(), xr.grad, wr.grad, br.grad
 
