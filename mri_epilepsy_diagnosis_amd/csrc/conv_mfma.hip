@@ -109,6 +109,39 @@ __global__ void pack_w_mfma_bf16_kernel(const float* __restrict__ w, bf16_t* __r
     }
 }
 
+// Weight image of the 8-output-channel variant (conv_mfma_fwd2_kernel<.., N8>): Wp[chunk][group 0..9][lane][s].  Row li of the
+// operand = channel li & 7 of row half hs = li >> 3; k-slot ks = lane >> 5 as in the images above.
+//   groups 2u, 2u+1 (class u = 0..3: k-slot taps (kd, kw) = (u, ks) for u < 3, (ks, 2) for u = 3):
+//       2u   (PAIR)   kh = hs         2u+1 (SINGLE) kh = 2, row half 0 only
+//   group 8: taps (kd 2, kh ks, kw 2), group 9: tap 26 in k-slot 0 — row half 0 only (the old groups 12 and 13)
+template <typename WT>
+__global__ void pack_w_mfma_n8_kernel(const float* __restrict__ w, WT* __restrict__ wp, int Co, int Ci, int dgrad, int nchunks) {
+    constexpr int PE = 16 / sizeof(WT);   // elements per lane fragment (4 fp32 / 8 bf16)
+    const int total = nchunks * 10 * 64 * PE;
+    const int Kc = dgrad ? Co : Ci;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        const int sidx = i % PE, lane = (i / PE) & 63;
+        int t = i / (PE * 64);
+        const int grp = t % 10, chunk = t / 10;
+        const int li = lane & 15, nc = li & 7, hs = li >> 3, ks = lane >> 5;
+        const int kc = chunk * 2 * PE + PE * ((lane >> 4) & 1) + sidx;
+        int tap = -1;
+        if (grp < 8) {
+            const int u = grp >> 1, single = grp & 1;
+            const int kd = u < 3 ? u : ks, kw = u < 3 ? ks : 2;
+            const int kh = single ? 2 : hs;
+            if (!(single && hs)) tap = (kd * 3 + kh) * 3 + kw;
+        } else if (grp == 8) {
+            if (!hs) tap = (2 * 3 + ks) * 3 + 2;
+        } else {
+            if (!hs && ks == 0) tap = 26;
+        }
+        float v = 0.f;
+        if (tap >= 0 && kc < Kc) v = dgrad ? w[((size_t)kc * Ci + nc) * 27 + (26 - tap)] : w[((size_t)nc * Ci + kc) * 27 + tap];
+        wp[i] = (WT)v;
+    }
+}
+
 // ------------------------------------------------------------------ forward / dgrad kernel
 // Persistent workgroups + double-buffered LDS + staging folded into the tap loop.
 //   A first version (round 1, removed) alternated "stage a chunk" and "27 tap groups of MFMA" with a barrier pair in between; the two
@@ -162,7 +195,14 @@ __device__ __forceinline__ float row_sum16(float v) {
 // statistics pass over y (one full read of every conv output, 0.5 ms per step of the U-Net) is not needed.  fp32 over a wave's
 // 8 x 16 voxels of a tile, float64 from there on: per wave in LDS, one partial per workgroup in `stat_part`
 // [gridDim.x][Nc][2], summed in a fixed order by norm_stats_finalize_kernel (deterministic: the tile -> workgroup map is static).
-template <typename T, int NT, bool STATS>
+// N8 (exactly 8 output channels: the first level of Modified3DUNet, modified_3dunet.py:33-55, and the 8 -> 16 data gradient of
+// the U-Net): a 16-row weight operand would be half zeros.  Its rows 8..15 take the SAME channels for the tap one halo row further
+// (kh + 1) instead: with the voxel fragment of halo row i, rows 0..7 add to output row i (tap kh) and rows 8..15 to output row
+// i - 1 (tap kh + 1).  A class of three tap groups (kh = 0, 1, 2: 3 x 8 row-MFMAs) becomes a PAIR group over halo rows 0..8 and
+// a SINGLE group (kh = 2) over rows 2..9: 17 row-MFMAs; 84 instead of 112 per chunk.  Nine accumulators (halo rows 0..8); the
+// epilogue adds the upper half of accumulator r + 1 (lanes 32..63) to the lower half of accumulator r (lanes 0..31).
+// Packed weights: pack_w_mfma_n8_kernel, 10 groups per chunk.
+template <typename T, int NT, bool STATS, bool N8 = false>
 __global__ void __launch_bounds__(256, 2)
 conv_mfma_fwd2_kernel(const T* __restrict__ x, const float* __restrict__ wp, const float* __restrict__ bias,
                       T* __restrict__ y, int N, int D, int H, int W, int Kc, int x_ld, int Nc, int y_ld, int NTT,
@@ -170,7 +210,9 @@ conv_mfma_fwd2_kernel(const T* __restrict__ x, const float* __restrict__ wp, con
     constexpr bool kBf16 = sizeof(T) == 2;
     constexpr int CK = 32 / sizeof(T);   // channels per 32-byte chunk (8 fp32 / 16 bf16)
     constexpr int PE = 16 / sizeof(T);   // channels per 16-byte piece
-    constexpr int CP = 8, TG = 14;       // CP: LDS voxel pitch in floats (32 bytes)
+    constexpr int CP = 8, TG = N8 ? 10 : 14;   // CP: LDS voxel pitch in floats (32 bytes); TG: weight fragments (groups) per chunk
+    static_assert(!N8 || (NT == 1 && !STATS), "the 8-channel variant has one N-tile and no fused statistics");
+    constexpr int AR = TH + (N8 ? 1 : 0);      // accumulator rows
     constexpr int BUF = kStg * 256 * 4;  // floats per LDS buffer: the halo tile rounded up to kStg 16-byte pieces per lane
     extern __shared__ __attribute__((aligned(16))) float lds[];
 
@@ -302,9 +344,9 @@ conv_mfma_fwd2_kernel(const T* __restrict__ x, const float* __restrict__ wp, con
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
-    f32x4 acc[TH][NT];
+    f32x4 acc[AR][NT];
 #pragma unroll
-    for (int m = 0; m < TH; ++m)
+    for (int m = 0; m < AR; ++m)
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) acc[m][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
 
@@ -328,7 +370,65 @@ conv_mfma_fwd2_kernel(const T* __restrict__ x, const float* __restrict__ wp, con
         }
         // MRI3D_EXPERIMENT_*: timing ablations of tuning builds (python -m mri_epilepsy_diagnosis_amd.build --variant ...;
         // results are wrong): see DESIGN.md §4.2 for the measured table.
-        if constexpr (NT == 1) {
+        if constexpr (N8) {
+            const Stage stn = stage_open(nxt, (it + 1) & 1, has_next);
+            const float* wtn = weights_of(nxt);
+            // units: four classes (a PAIR and a SINGLE group on one set of 10 row fragments), then the old groups 12 and 13
+            constexpr int NU = 6;
+            f32x4 fr[2][TH + 2];
+            {
+                const int o0 = a_off(0);
+#pragma unroll
+                for (int i = 0; i < TH + 2; ++i) fr[0][i] = *reinterpret_cast<const f32x4*>(bufc + o0 + i * HW * CP);
+            }
+#pragma unroll
+            for (int g = 0; g < TG; ++g) {
+                const int u = g < 8 ? g / 2 : g - 4, ng = u < 4 ? 2 : 1, gi = u < 4 ? g - 2 * u : 0;
+                stage_group(nxt, stn, g);
+                if (g >= 1) bqa[g - 1] = *reinterpret_cast<const f32x4*>(wtn + (size_t)(g - 1) * wstep);   // next item's
+                if (u + 1 < NU) {   // this group's share of the next unit's fragments
+                    const int nu = u + 1, nfirst = nu < 4 ? 3 * nu : nu + 8, nf = nu < 4 ? TH + 2 : TH;
+                    const int on = a_off(nfirst);
+#pragma unroll
+                    for (int i = 0; i < TH + 2; ++i)
+                        if (i >= gi * nf / ng && i < (gi + 1) * nf / ng)
+                            fr[nu & 1][i] = *reinterpret_cast<const f32x4*>(bufc + on + i * HW * CP);
+                }
+                __builtin_amdgcn_sched_barrier(0);  // keep the prefetches above this group's MFMAs
+                // PAIR group: halo rows 0..8 -> accumulators 0..8; SINGLE group (kh = 2): halo rows 2..9 -> accumulators 0..7;
+                // groups 8, 9: halo rows 0..7 -> accumulators 0..7
+                const int r0 = (u < 4 && gi == 1) ? 2 : 0, nr = (u < 4 && gi == 0) ? TH + 1 : TH;
+                if constexpr (kBf16) {
+#pragma unroll
+                    for (int m = 0; m < TH + 1; ++m)
+                        if (m < nr)
+                            acc[m][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, bqa[g]),
+                                                                                __builtin_bit_cast(bf16x8_t, fr[u & 1][m + r0]),
+                                                                                acc[m][0], 0, 0, 0);
+                } else {
+#pragma unroll
+                    for (int m = 0; m < TH; m += 2)
+#pragma unroll
+                        for (int s4 = 0; s4 < 4; ++s4) {
+                            acc[m][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(bqa[g][s4], fr[u & 1][m + r0][s4], acc[m][0], 0, 0, 0);
+                            acc[m + 1][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(bqa[g][s4], fr[u & 1][m + 1 + r0][s4], acc[m + 1][0], 0, 0, 0);
+                        }
+                    if (nr == TH + 1) {
+#pragma unroll
+                        for (int s4 = 0; s4 < 4; ++s4)
+                            acc[TH][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(bqa[g][s4], fr[u & 1][TH][s4], acc[TH][0], 0, 0, 0);
+                    }
+                }
+            }
+            bqa[TG - 1] = *reinterpret_cast<const f32x4*>(wtn + (size_t)(TG - 1) * wstep);
+            if (cur.ch == nchunks - 1) {
+                // fold: output row r = lower half of accumulator r + upper half (lanes 32..63 -> 0..31) of accumulator r + 1
+#pragma unroll
+                for (int m = 0; m < TH; ++m)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) acc[m][0][r] += __shfl_down(acc[m + 1][0][r], 32, 64);
+            }
+        } else if constexpr (NT == 1) {
             // One N-tile: every A-fragment feeds a single MFMA chain, so the LDS reads are the largest non-MFMA cost.  The tap
             // groups come in UNITS: four classes of three groups that differ only by one halo row (pair_tap), then groups 12
             // and 13.  A class needs 10 row fragments (rows 0..9 of its kh = 0 group; group kh, output row m uses row m + kh)
@@ -511,13 +611,14 @@ conv_mfma_fwd2_kernel(const T* __restrict__ x, const float* __restrict__ wp, con
                 }
             }
 #pragma unroll
-            for (int m = 0; m < TH; ++m)
+            for (int m = 0; m < AR; ++m)
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) acc[m][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
         }
         // The DMA pieces of the next item are OLDER than the >= 12 weight loads issued after them in this iteration, and VMEM
-        // returns in order: at most 6 operations outstanding means every piece has landed in LDS.
-        asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        // returns in order: at most that many operations outstanding means every piece has landed in LDS.
+        constexpr int kYounger = N8 ? 2 : 6;   // VMEM operations certainly issued after the last DMA piece (weight reloads)
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kYounger) : "memory");
 #if !defined(MRI3D_EXPERIMENT_NO_CHUNK_BARRIER)   // tuning builds only: timing ablation, results are wrong without it
         __syncthreads();  // buffer (it+1)&1 is complete; buffer it&1 may be overwritten from the next iteration on
 #endif
@@ -868,7 +969,16 @@ static int run_mfma_fwd(const Mri3dConvGeom& g, bool dgrad, const void* in_v, co
         MRI3D_DISPATCH_DTYPE(g.dtype, T, { launch_direct<T>(dp, (const T*)in_v, wp, bias, (T*)out_v, s); });
         return check_launch(dgrad ? "conv3d_dgrad(mfma direct)" : "conv3d_fwd(mfma direct)");
     }
-    if (g.dtype == MRI3D_BF16)   // same image size in bytes: 256 floats == 512 bf16 per (chunk, tg, nt)
+    const bool n8 = Nc == 8 && stat_part == nullptr;   // exactly 8 output channels: the row-paired variant (10 groups per chunk)
+    if (n8) {
+        const int ptotal = p.nchunks * 10 * 256;   // 16-byte fragments x 64 lanes, in 4-byte units
+        if (g.dtype == MRI3D_BF16)
+            hipLaunchKernelGGL(pack_w_mfma_n8_kernel<bf16_t>, dim3(std::min(cdiv(2 * ptotal, 256), 2048)), dim3(256), 0, s, w,
+                               reinterpret_cast<bf16_t*>(wp), g.co, g.ci, dgrad ? 1 : 0, p.nchunks);
+        else
+            hipLaunchKernelGGL(pack_w_mfma_n8_kernel<float>, dim3(std::min(cdiv(ptotal, 256), 2048)), dim3(256), 0, s, w, wp, g.co,
+                               g.ci, dgrad ? 1 : 0, p.nchunks);
+    } else if (g.dtype == MRI3D_BF16)   // same image size in bytes: 256 floats == 512 bf16 per (chunk, tg, nt)
         hipLaunchKernelGGL(pack_w_mfma_bf16_kernel, dim3(std::min(cdiv(2 * total, 256), 2048)), dim3(256), 0, s, w,
                            reinterpret_cast<bf16_t*>(wp), g.co, g.ci, dgrad ? 1 : 0, p.NTT, p.nchunks);
     else
@@ -878,9 +988,9 @@ static int run_mfma_fwd(const Mri3dConvGeom& g, bool dgrad, const void* in_v, co
     const size_t smem = p.smem + (stat_part ? p.stat_smem : 0);
     constexpr int kMaxSmem = 2 * kStg * 256 * 16 + 4 * 8 * 16 * 2 * 8;   // two halo buffers + float64 statistics of up to 128 channels
     MRI3D_REQUIRE(smem <= (size_t)kMaxSmem, MRI3D_ENOTSUP, "conv3d(mfma): too many output channels for fused statistics");
-#define MRI3D_FWD2_CASE(NTv, STv)                                                                                     \
-    if (p.NT == NTv && (stat_part != nullptr) == STv) {                                                               \
-        auto kern = conv_mfma_fwd2_kernel<T, NTv, STv>;                                                               \
+#define MRI3D_FWD2_CASE(NTv, STv, N8v)                                                                                \
+    if (p.NT == NTv && (stat_part != nullptr) == STv && n8 == N8v) {                                                  \
+        auto kern = conv_mfma_fwd2_kernel<T, NTv, STv, N8v>;                                                          \
         static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),                       \
                                                            hipFuncAttributeMaxDynamicSharedMemorySize, kMaxSmem);     \
         (void)attr;   /* once per kernel, not per launch */                                                          \
@@ -889,10 +999,11 @@ static int run_mfma_fwd(const Mri3dConvGeom& g, bool dgrad, const void* in_v, co
                            stat_part);                                                                                \
     }
     MRI3D_DISPATCH_DTYPE(g.dtype, T, {
-        MRI3D_FWD2_CASE(1, false)
-        MRI3D_FWD2_CASE(2, false)
-        MRI3D_FWD2_CASE(1, true)
-        MRI3D_FWD2_CASE(2, true)
+        MRI3D_FWD2_CASE(1, false, false)
+        MRI3D_FWD2_CASE(2, false, false)
+        MRI3D_FWD2_CASE(1, true, false)
+        MRI3D_FWD2_CASE(2, true, false)
+        MRI3D_FWD2_CASE(1, false, true)
     });
 #undef MRI3D_FWD2_CASE
     return check_launch(dgrad ? "conv3d_dgrad(mfma)" : "conv3d_fwd(mfma)");

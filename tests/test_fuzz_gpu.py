@@ -76,6 +76,19 @@ def test_conv3x3x3_many_small_volumes(case, dtype):
     _run_conv_case(case, dtype)
 
 
+# exactly 8 output channels in the forward (8 -> 8, 16 -> 8, 24 -> 8) or in the data gradient (8 -> 16, 8 -> 32): the row-paired
+# variant of the tiled MFMA kernel (two taps share the 16-row weight operand, 9 accumulators, halves folded in the epilogue);
+# big enough for the tiled path (>= 256 tiles) and ragged in every axis; pitched slices; one case with a single chunk
+N8_CASES = [(2, 8, 8, 21, 35, 50, 0, 0, 71), (1, 16, 8, 17, 40, 65, 8, 8, 72), (2, 24, 8, 9, 33, 47, 0, 0, 73),
+            (1, 8, 16, 13, 41, 70, 0, 8, 74), (1, 8, 32, 9, 34, 49, 8, 0, 75), (40, 8, 8, 4, 8, 16, 0, 0, 76)]
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
+@pytest.mark.parametrize("case", N8_CASES, ids=lambda c: "n%d_%d-%d_%dx%dx%d_p%d_%d" % c[:8])
+def test_conv3x3x3_eight_output_channels(case, dtype):
+    _run_conv_case(case, dtype)
+
+
 # stride-2 3x3x3 layers (modified_3dunet.py:23-38, cnn_model.py:49-81) on the LDS-free MFMA kernel: forward over output M-tiles,
 # data gradient over same-parity input M-tiles with wave-uniform tap sets; even / odd extents (the last output voxel then has no
 # kw = 2 neighbour), pitched slices, few units (a workgroup per unit, taps split over its waves) and many, Kc = 8 (half a chunk)
