@@ -233,3 +233,66 @@ def test_single_output_channel_convs(case):
     close(wg.grad, w64.grad, "dw")
     if bias:
         close(bg.grad, b64.grad, "db")
+
+
+def test_conv_tensors_with_more_than_2_31_elements():
+    """288 GB of HBM invite batches whose activation tensors exceed 2^31 ELEMENTS (12 x 48 x 160x192x160 = 2.83e9, 11.3 GB in fp32):
+    every voxel index in the kernels must be 64-bit (or relative to a per-item origin).  Size-independent property: the kernels are
+    deterministic per output voxel, so the last volume of the big batch must equal — bit for bit — the same volume convolved alone
+    (forward and data gradient), and the weight gradient of the batch must equal the sum of the per-volume weight gradients."""
+    nb, ci, co, shape = 12, 48, 16, (160, 192, 160)
+    g = torch.Generator(device="cuda").manual_seed(5)
+    x = torch.empty((nb, ci) + shape, device="cuda", memory_format=torch.channels_last_3d)
+    assert x.numel() > 2 ** 31
+    for i in range(nb):                       # generated volume by volume (a single randn of 11 GB is its own stress test)
+        x[i].copy_(torch.randn((ci,) + shape, device="cuda", generator=g).unsqueeze(0).contiguous(memory_format=torch.channels_last_3d)[0])
+    wt = (torch.randn(co, ci, 3, 3, 3, device="cuda", generator=g) / np.sqrt(27 * ci))
+    b = torch.randn(co, device="cuda", generator=g)
+    dy = torch.randn((nb, co) + shape, device="cuda", generator=g).contiguous(memory_format=torch.channels_last_3d)
+
+    def run(xs, dys):
+        xs = xs.detach().requires_grad_(True)
+        w, bb = wt.clone().requires_grad_(True), b.clone().requires_grad_(True)
+        y = ops.conv3d(xs, w, bb, padding=1)
+        y.backward(dys)
+        return y.detach(), xs.grad, w.grad, bb.grad
+
+    y_all, dx_all, dw_all, db_all = run(x, dy)
+    dw_sum, db_sum = torch.zeros_like(dw_all, dtype=torch.float64), torch.zeros_like(db_all, dtype=torch.float64)
+    for i in (0, nb // 2, nb - 1):
+        y_i, dx_i, _, _ = run(x[i:i + 1], dy[i:i + 1])
+        assert torch.equal(y_all[i:i + 1], y_i), "forward of volume %d differs inside the big batch" % i
+        assert torch.equal(dx_all[i:i + 1], dx_i), "data gradient of volume %d differs inside the big batch" % i
+    del y_all, dx_all
+    for i in range(nb):
+        _, _, dw_i, db_i = run(x[i:i + 1], dy[i:i + 1])
+        dw_sum += dw_i.double()
+        db_sum += db_i.double()
+    assert torch.allclose(dw_all.double(), dw_sum, rtol=2e-5, atol=2e-5 * float(dw_sum.abs().max()))
+    assert torch.allclose(db_all.double(), db_sum, rtol=2e-5, atol=2e-5 * float(db_sum.abs().max()))
+
+
+def test_streaming_ops_on_tensors_with_more_than_2_31_elements():
+    """Same property for the per-sample streaming operators (InstanceNorm + LeakyReLU, MaxPool3d, trilinear x2 on the pooled
+    tensor) on a 2.83e9-element activation tensor: volume i of the batch result equals the operator on volume i alone, forward
+    and backward, bit for bit."""
+    nb, c, shape = 12, 48, (160, 192, 160)
+    g = torch.Generator(device="cuda").manual_seed(6)
+    x = torch.empty((nb, c) + shape, device="cuda", memory_format=torch.channels_last_3d)
+    for i in range(nb):
+        x[i].copy_(torch.randn((c,) + shape, device="cuda", generator=g).unsqueeze(0).contiguous(memory_format=torch.channels_last_3d)[0])
+    assert x.numel() > 2 ** 31
+
+    def run(xs):
+        xs = xs.detach().requires_grad_(True)
+        z = ops.norm_act(xs, None, None, None, None, None, "instance", 0.1, 1e-5, "leaky_relu", 0.01)
+        p = ops.max_pool3d(z, 2)
+        u = ops.upsample3d(p, scale_factor=2, mode="trilinear", align_corners=False)
+        (u * u).sum().backward()
+        return z.detach(), p.detach(), u.detach(), xs.grad
+
+    big = run(x)
+    for i in (0, nb - 1):
+        one = run(x[i:i + 1])
+        for name, a, r in zip(("norm_act", "max_pool", "upsample", "dx"), big, one):
+            assert torch.equal(a[i:i + 1], r), "%s of volume %d differs inside the big batch" % (name, i)
