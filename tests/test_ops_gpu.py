@@ -534,3 +534,24 @@ def test_batchnorm_statistics_from_the_conv_epilogue_equal_the_statistics_pass(c
         m, v = yr.mean(dim=(0, 2, 3, 4)), yr.var(dim=(0, 2, 3, 4), unbiased=True)
         assert torch.allclose(res[1][1].cpu(), 0.1 * m, rtol=1e-4, atol=1e-5)
         assert torch.allclose(res[1][2].cpu(), 0.9 + 0.1 * v, rtol=1e-4, atol=1e-5)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
+def test_max_pool3d_2_nan_and_index_semantics_equal_torch(dtype):
+    """MaxPool3d(2) on even extents (the eight-loads-at-once kernel): NaNs propagate, the FIRST maximum of a window wins, and the
+    gradient lands on torch's arg-max voxel — on a tensor with repeated values and NaNs sprinkled in."""
+    g = torch.Generator().manual_seed(12)
+    x = torch.randint(-3, 4, (2, 16, 6, 8, 10), generator=g).float()       # many ties
+    x[torch.rand(x.shape, generator=g) < 0.02] = float("nan")
+    xr = x.clone().requires_grad_(True)
+    yr = F.max_pool3d(xr, 2)
+    gy = torch.randn(yr.shape, generator=g)
+    if dtype == torch.bfloat16:
+        gy = gy.to(dtype).float()
+    yr.backward(gy)
+    xd = _dev(x, False).to(dtype).requires_grad_(True)
+    yd = ops.max_pool3d(xd, 2)
+    yd.backward(_dev(gy, False).to(dtype))
+    a, r = to_ncdhw(yd).float().cpu(), yr.detach()
+    assert torch.equal(torch.isnan(a), torch.isnan(r)) and torch.equal(a[~torch.isnan(r)], r[~torch.isnan(r)])
+    assert torch.equal(to_ncdhw(xd.grad).float().cpu(), xr.grad)
