@@ -77,6 +77,24 @@ int mri3d_conv3d_dgrad(const Mri3dConvGeom* g, const void* dy, const void* w, co
 int mri3d_conv3d_wgrad(const Mri3dConvGeom* g, const void* x, const void* dy, void* dw, void* dbias,
                        void* workspace, size_t ws_bytes, mri3d_stream_t stream);
 
+/* Convolution over torch.cat((x, x2), dim=1) WITHOUT the concatenation — `unet.UNet`'s decoder, x = cat((skip, upsampled))
+ * in front of its first ConvolutionalBlock (segmentation/routine.py:346-356 -> unet DecodingBlock.forward).  g describes the
+ * concatenated convolution (g->ci = all input channels, g->x_ld = voxel pitch of x); channels [0, split) are read from x,
+ * channels [split, ci) from x2 (voxel pitch x2_ld).  The data gradient is written as two dense tensors dx (pitch g->x_ld) and
+ * dx2 (pitch dx2_ld); the weight gradient reads both.  Workspace sizes are those of the plain passes
+ * (mri3d_conv3d_workspace_bytes).  stat_partials (may be NULL): as in mri3d_conv3d_fwd_stats.
+ * mri3d_conv3d_cat_supported(g, split, second_ld, pass) = 1 when the pass is served (3x3x3 / stride 1 / pad 1 on the tiled MFMA
+ * kernels, split a multiple of 16, every pointer 16-byte aligned); otherwise concatenate (mri3d_copy_channels) and call the plain
+ * entry points. */
+int32_t mri3d_conv3d_cat_supported(const Mri3dConvGeom* g, int32_t split, int32_t second_ld, int32_t pass);
+int mri3d_conv3d_fwd_cat(const Mri3dConvGeom* g, const void* x, const void* x2, int32_t split, int32_t x2_ld, const void* w,
+                         const void* bias, void* y, double* stat_partials, void* workspace, size_t ws_bytes,
+                         mri3d_stream_t stream);
+int mri3d_conv3d_dgrad_cat(const Mri3dConvGeom* g, const void* dy, const void* w, void* dx, void* dx2, int32_t split,
+                           int32_t dx2_ld, void* workspace, size_t ws_bytes, mri3d_stream_t stream);
+int mri3d_conv3d_wgrad_cat(const Mri3dConvGeom* g, const void* x, const void* x2, int32_t split, int32_t x2_ld, const void* dy,
+                           void* dw, void* dbias, void* workspace, size_t ws_bytes, mri3d_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------------
  * BatchNorm3d / InstanceNorm3d fused with the following activation — replaces
  * nn.BatchNorm3d + nn.PReLU (unet.UNet ConvolutionalBlock), nn.BatchNorm3d + LeakyReLU/ReLU

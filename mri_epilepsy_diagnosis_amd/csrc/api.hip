@@ -33,6 +33,13 @@ int conv_mfma_dgrad(const Mri3dConvGeom& g, const void* dy, const float* w, cons
 int conv_mfma_wgrad(const Mri3dConvGeom& g, const void* x, const void* dy, float* dw, float* dbias, void* ws,
                     size_t ws_bytes, hipStream_t s);
 int conv_mfma_fwd_stat_blocks(const Mri3dConvGeom& g);
+bool conv_mfma_cat_supported(const Mri3dConvGeom& g, int split, int second_ld, int pass);
+int conv_mfma_fwd_cat(const Mri3dConvGeom& g, const void* x, const void* x2, int split, int x2_ld, const float* w, const float* bias,
+                      void* y, double* stat_part, void* ws, size_t ws_bytes, hipStream_t s);
+int conv_mfma_dgrad_cat(const Mri3dConvGeom& g, const void* dy, const float* w, void* dx, void* dx2, int split, int dx2_ld, void* ws,
+                        size_t ws_bytes, hipStream_t s);
+int conv_mfma_wgrad_cat(const Mri3dConvGeom& g, const void* x, const void* x2, int split, int x2_ld, const void* dy, float* dw,
+                        float* dbias, void* ws, size_t ws_bytes, hipStream_t s);
 int conv_mfma_fwd_stats(const Mri3dConvGeom& g, const void* x, const float* w, const float* bias, void* y, double* stat_part,
                         void* ws, size_t ws_bytes, hipStream_t s);
 
@@ -47,7 +54,9 @@ int conv_pointwise_wgrad(const Mri3dConvGeom& g, const void* x, const void* dy, 
 // the MFMA kernels move 16-byte pieces: a pitched channel slice whose base is not 16-byte aligned (legal for the generic
 // kernels) must not be routed to them
 
-static int conv_check(const Mri3dConvGeom* g, const char* who) {
+// first_ci >= 0: the input is split over two tensors (the *_cat entry points) and x_ld is the pitch of the first, which holds
+// first_ci channels
+static int conv_check(const Mri3dConvGeom* g, const char* who, int first_ci = -1) {
     MRI3D_REQUIRE(g != nullptr, MRI3D_EINVAL, "%s: null geometry", who);
     MRI3D_REQUIRE(g->dtype == MRI3D_F32 || g->dtype == MRI3D_BF16, MRI3D_ENOTSUP, "%s: unknown dtype %d", who, g->dtype);
     MRI3D_REQUIRE(g->n > 0 && g->di > 0 && g->hi > 0 && g->wi > 0 && g->ci > 0 && g->dout > 0 && g->ho > 0 && g->wo > 0 &&
@@ -56,7 +65,7 @@ static int conv_check(const Mri3dConvGeom* g, const char* who) {
     MRI3D_REQUIRE(g->kd > 0 && g->kh > 0 && g->kw > 0 && g->sd > 0 && g->sh > 0 && g->sw > 0 && g->dd > 0 && g->dh > 0 &&
                       g->dw > 0 && g->pd >= 0 && g->ph >= 0 && g->pw >= 0,
                   MRI3D_EINVAL, "%s: bad kernel/stride/padding/dilation", who);
-    MRI3D_REQUIRE(g->x_ld >= g->ci && g->y_ld >= g->co, MRI3D_EINVAL, "%s: pitch smaller than channel count", who);
+    MRI3D_REQUIRE(g->x_ld >= (first_ci >= 0 ? first_ci : g->ci) && g->y_ld >= g->co, MRI3D_EINVAL, "%s: pitch smaller than channel count", who);
     // torch: out = floor((in + 2p - d(k-1) - 1)/s) + 1
     int ed = (g->di + 2 * g->pd - g->dd * (g->kd - 1) - 1) / g->sd + 1;
     int eh = (g->hi + 2 * g->ph - g->dh * (g->kh - 1) - 1) / g->sh + 1;
@@ -121,6 +130,47 @@ extern "C" int mri3d_conv3d_dgrad(const Mri3dConvGeom* g, const void* dy, const 
     if (conv_mfma_supported(*g, MRI3D_PASS_DGRAD) && aligned16(dy, dx, workspace))
         return conv_mfma_dgrad(*g, dy, (const float*)w, (const float*)bias, dx, workspace, ws_bytes, s);
     return conv_generic_dgrad(*g, dy, (const float*)w, (const float*)bias, dx, workspace, ws_bytes, s);
+}
+
+// ---- convolution over torch.cat((x, x2), dim=1) without the concatenation (unet.UNet decoder: cat((skip, upsampled)))
+extern "C" int32_t mri3d_conv3d_cat_supported(const Mri3dConvGeom* g, int32_t split, int32_t second_ld, int32_t pass) {
+    if (!g || split <= 0 || conv_check(g, "conv3d_cat_supported", split) != MRI3D_OK) return 0;
+    return conv_mfma_cat_supported(*g, split, second_ld, pass) ? 1 : 0;
+}
+
+extern "C" int mri3d_conv3d_fwd_cat(const Mri3dConvGeom* g, const void* x, const void* x2, int32_t split, int32_t x2_ld,
+                                    const void* w, const void* bias, void* y, double* stat_partials, void* workspace,
+                                    size_t ws_bytes, mri3d_stream_t stream) {
+    int rc = conv_check(g, "conv3d_fwd_cat", split);
+    if (rc) return rc;
+    MRI3D_REQUIRE(x && x2 && w && y, MRI3D_EINVAL, "conv3d_fwd_cat: null pointer");
+    MRI3D_REQUIRE(conv_mfma_cat_supported(*g, split, x2_ld, MRI3D_PASS_FWD) && aligned16(x, y, workspace) && aligned16(x2),
+                  MRI3D_ENOTSUP, "conv3d_fwd_cat: geometry / alignment not served (query mri3d_conv3d_cat_supported)");
+    MRI3D_REQUIRE(stat_partials == nullptr || conv_mfma_fwd_stat_blocks(*g) > 0, MRI3D_ENOTSUP, "conv3d_fwd_cat: no fused statistics for this geometry");
+    return conv_mfma_fwd_cat(*g, x, x2, split, x2_ld, (const float*)w, (const float*)bias, y, stat_partials, workspace, ws_bytes,
+                             static_cast<hipStream_t>(stream));
+}
+
+extern "C" int mri3d_conv3d_dgrad_cat(const Mri3dConvGeom* g, const void* dy, const void* w, void* dx, void* dx2, int32_t split,
+                                      int32_t dx2_ld, void* workspace, size_t ws_bytes, mri3d_stream_t stream) {
+    int rc = conv_check(g, "conv3d_dgrad_cat", split);
+    if (rc) return rc;
+    MRI3D_REQUIRE(dy && w && dx && dx2, MRI3D_EINVAL, "conv3d_dgrad_cat: null pointer");
+    MRI3D_REQUIRE(conv_mfma_cat_supported(*g, split, dx2_ld, MRI3D_PASS_DGRAD) && aligned16(dy, dx, workspace) && aligned16(dx2),
+                  MRI3D_ENOTSUP, "conv3d_dgrad_cat: geometry / alignment not served (query mri3d_conv3d_cat_supported)");
+    return conv_mfma_dgrad_cat(*g, dy, (const float*)w, dx, dx2, split, dx2_ld, workspace, ws_bytes, static_cast<hipStream_t>(stream));
+}
+
+extern "C" int mri3d_conv3d_wgrad_cat(const Mri3dConvGeom* g, const void* x, const void* x2, int32_t split, int32_t x2_ld,
+                                      const void* dy, void* dw, void* dbias, void* workspace, size_t ws_bytes,
+                                      mri3d_stream_t stream) {
+    int rc = conv_check(g, "conv3d_wgrad_cat", split);
+    if (rc) return rc;
+    MRI3D_REQUIRE(x && x2 && dy && dw, MRI3D_EINVAL, "conv3d_wgrad_cat: null pointer");
+    MRI3D_REQUIRE(conv_mfma_cat_supported(*g, split, x2_ld, MRI3D_PASS_WGRAD) && aligned16(x, dy, workspace) && aligned16(x2),
+                  MRI3D_ENOTSUP, "conv3d_wgrad_cat: geometry / alignment not served (query mri3d_conv3d_cat_supported)");
+    return conv_mfma_wgrad_cat(*g, x, x2, split, x2_ld, dy, (float*)dw, (float*)dbias, workspace, ws_bytes,
+                               static_cast<hipStream_t>(stream));
 }
 
 extern "C" int mri3d_conv3d_wgrad(const Mri3dConvGeom* g, const void* x, const void* dy, void* dw, void* dbias,

@@ -206,7 +206,12 @@ template <typename T, int NT, bool STATS, bool N8 = false>
 __global__ void __launch_bounds__(256, 2)
 conv_mfma_fwd2_kernel(const T* __restrict__ x, const float* __restrict__ wp, const float* __restrict__ bias,
                       T* __restrict__ y, int N, int D, int H, int W, int Kc, int x_ld, int Nc, int y_ld, int NTT,
-                      int gy, int tilesD, int tilesH, int tilesW, int ntiles, double* __restrict__ stat_part) {
+                      int gy, int tilesD, int tilesH, int tilesW, int ntiles, double* __restrict__ stat_part,
+                      const T* __restrict__ x2, int x2_ld, int ksplit, T* __restrict__ y2, int y2_ld, int nsplit) {
+    // x2 (forward of a conv over cat((x, x2), channels)): input channels >= ksplit live in the second tensor with its own pitch —
+    // a chunk's DMA resource is simply based in the tensor that holds it, so torch.cat never materialises (unet.UNet decoder,
+    // segmentation/routine.py:346-356).  y2 (its data gradient): output channels >= nsplit are written to the second tensor, so
+    // both gradients come out dense.  ksplit, nsplit are multiples of 16; x2 = y2 = nullptr: one tensor each.
     constexpr bool kBf16 = sizeof(T) == 2;
     constexpr int CK = 32 / sizeof(T);   // channels per 32-byte chunk (8 fp32 / 16 bf16)
     constexpr int PE = 16 / sizeof(T);   // channels per 16-byte piece
@@ -252,12 +257,13 @@ conv_mfma_fwd2_kernel(const T* __restrict__ x, const float* __restrict__ wp, con
     // ... and its BYTE offset from the item's halo origin (voxel (d0-1, h0-1, w0-1), channel ch*CK): the DMA's buffer resource
     // is based at that origin, so an in-volume piece's offset is this per-lane constant — no per-piece integer multiplies,
     // clamps or 64-bit arithmetic — and an out-of-volume piece gets the out-of-range offset that makes the DMA write zeros.
-    unsigned frel[kStg];
+    unsigned vrel[kStg];   // voxel index relative to the halo origin; byte offset = vrel * pitch bytes + the lane's piece (one v_mad)
 #pragma unroll
     for (int j = 0; j < kStg; ++j) {
         const int r = srel[j];
-        frel[j] = (unsigned)((((r >> 16) * H + ((r >> 8) & 0xff)) * W + (r & 0xff)) * x_ld + PE * (tid & 1)) * (unsigned)sizeof(T);
+        vrel[j] = (unsigned)(((r >> 16) * H + ((r >> 8) & 0xff)) * W + (r & 0xff));
     }
+    const unsigned pieceb = (unsigned)(PE * (tid & 1)) * (unsigned)sizeof(T);
 
     struct Item { int n, d0, h0, w0, nt0, ch; };
     auto decode = [&](int it) -> Item {
@@ -282,14 +288,18 @@ conv_mfma_fwd2_kernel(const T* __restrict__ x, const float* __restrict__ wp, con
     // `tid` = 16-byte piece j*256 + tid of the [halo voxel][32 B] image — lane-linear, which is what an LDS-DMA writes.
     // Tiles whose halo lies inside the volume (70 % at 160x192x160) take the wave-uniform fast path: the offsets are the
     // per-lane constants, no VALU work at all.  (Pieces past the tile's end alias voxel 0 and land in the buffer's padding.)
-    struct Stage { i32x4 rs; unsigned dst; bool interior, on; };
+    struct Stage { i32x4 rs; unsigned dst, ldb; bool interior, on; };
     auto stage_open = [&](const Item& it, int bsel, bool on) -> Stage {
         Stage st;
+        const bool second = x2 != nullptr && it.ch * CK >= ksplit;   // wave-uniform: which tensor holds this chunk
+        const T* xs = second ? x2 : x;
+        const int ld = second ? x2_ld : x_ld, c0 = second ? it.ch * CK - ksplit : it.ch * CK;
+        st.ldb = (unsigned)ld * (unsigned)sizeof(T);
 #if defined(MRI3D_EXPERIMENT_SAME_TILE)   // every item stages the same (interior) tile: all pieces are L2 hits, no fabric traffic
-        const unsigned long long org = (unsigned long long)(x + ((((int64_t)(TD - 1) * H + TH - 1) * W + TW - 1) * x_ld + it.ch * CK));
+        const unsigned long long org = (unsigned long long)(xs + ((((int64_t)(TD - 1) * H + TH - 1) * W + TW - 1) * ld + c0));
 #else
         const unsigned long long org =
-            (unsigned long long)(x + (((((int64_t)it.n * D + it.d0 - 1) * H + it.h0 - 1) * W + it.w0 - 1) * x_ld + it.ch * CK));
+            (unsigned long long)(xs + (((((int64_t)it.n * D + it.d0 - 1) * H + it.h0 - 1) * W + it.w0 - 1) * ld + c0));
 #endif
         // raw buffer resource: base (48 bits), stride 0, num_records, gfx9 raw-dword format
         st.rs[0] = __builtin_amdgcn_readfirstlane((int)(unsigned)(org & 0xffffffffu));
@@ -305,13 +315,13 @@ conv_mfma_fwd2_kernel(const T* __restrict__ x, const float* __restrict__ wp, con
     auto stage_piece = [&](const Item& it, const Stage& st, int j) {   // wave-uniform branches only
         if (!st.on) return;
         if (st.interior) {
-            lds_dma16(frel[j], st.rs, st.dst + j * 4096);
+            lds_dma16(vrel[j] * st.ldb + pieceb, st.rs, st.dst + j * 4096);
         } else {
             const int r = srel[j];
             const int gd = it.d0 - 1 + (r >> 16), gh = it.h0 - 1 + ((r >> 8) & 0xff), gw = it.w0 - 1 + (r & 0xff);
             const bool ok = (unsigned)gd < (unsigned)D && (unsigned)gh < (unsigned)H && (unsigned)gw < (unsigned)W &&
                             it.ch * CK + PE * (tid & 1) < Kc;
-            lds_dma16(ok ? frel[j] : kDmaOob, st.rs, st.dst + j * 4096);
+            lds_dma16(ok ? vrel[j] * st.ldb + pieceb : kDmaOob, st.rs, st.dst + j * 4096);
         }
     };
     // pieces issued in front of tap group tg: kPpt per group, so that a wave's issue slots (~60-180 cycles per piece) are
@@ -548,7 +558,10 @@ conv_mfma_fwd2_kernel(const T* __restrict__ x, const float* __restrict__ wp, con
                 for (int nt = 0; nt < NT; ++nt) {
                     const int co = (cur.nt0 + nt) * 16 + 4 * kq;
                     if (co < Nc) {
-                        const bool vec = (co + 3 < Nc) && ((y_ld & 3) == 0);
+                        const bool second = y2 != nullptr && co >= nsplit;   // uniform per N-tile (nsplit % 16 == 0)
+                        T* const yd = second ? y2 : y;
+                        const int yld = second ? y2_ld : y_ld, cd = second ? co - nsplit : co;
+                        const bool vec = (co + 3 < Nc) && ((yld & 3) == 0);
                         float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
                         if (bias) {
                             bv.x = bias[co];
@@ -565,7 +578,7 @@ conv_mfma_fwd2_kernel(const T* __restrict__ x, const float* __restrict__ wp, con
                         for (int m = 0; m < TH; ++m) {
                             const int oh = cur.h0 + m;
                             if (oh < H && ow < W) {
-                                T* yp = y + ((((int64_t)cur.n * D + od) * H + oh) * W + ow) * y_ld + co;
+                                T* yp = yd + ((((int64_t)cur.n * D + od) * H + oh) * W + ow) * yld + cd;
                                 const f32x4 a = acc[m][nt];
                                 if (vec) {
                                     stf4(yp, make_float4(a[0] + bv.x, a[1] + bv.y, a[2] + bv.z, a[3] + bv.w));
@@ -940,8 +953,13 @@ static bool mfma_fwd_plan(const Mri3dConvGeom& g, bool dgrad, MfmaFwdPlan& p) {
     return true;
 }
 
+// second tensor of a split operand (conv over cat((x, x2), channels) / its data gradient written to two tensors): channels
+// >= split live in `second` (pitch second_ld); second == nullptr: none
+struct ConvSplit { const void* second; int split, second_ld; };
+
 static int run_mfma_fwd(const Mri3dConvGeom& g, bool dgrad, const void* in_v, const float* w, const float* bias,
-                        void* out_v, void* ws, size_t ws_bytes, hipStream_t s, double* stat_part = nullptr) {
+                        void* out_v, void* ws, size_t ws_bytes, hipStream_t s, double* stat_part = nullptr,
+                        ConvSplit sp = ConvSplit{nullptr, 0, 0}) {
     MfmaFwdPlan p;
     DirectPlan dp;
     const bool strided = direct_only(g);
@@ -961,6 +979,7 @@ static int run_mfma_fwd(const Mri3dConvGeom& g, bool dgrad, const void* in_v, co
     const int Kc = dgrad ? g.co : g.ci, Nc = dgrad ? g.ci : g.co;
     const int in_ld = dgrad ? g.y_ld : g.x_ld, out_ld = dgrad ? g.x_ld : g.y_ld;
     int total = (int)p.wp_floats;
+    MRI3D_REQUIRE(sp.second == nullptr || (!p.small && !strided), MRI3D_ENOTSUP, "conv3d(mfma): split operands need the tiled kernel");
     if (p.small && stat_part == nullptr) {
         if (!strided) MRI3D_REQUIRE(direct_plan(g, dgrad, dp), MRI3D_ENOTSUP, "conv3d(mfma): unsupported geometry");
         const int stotal = (int)dp.wp_floats;
@@ -988,6 +1007,10 @@ static int run_mfma_fwd(const Mri3dConvGeom& g, bool dgrad, const void* in_v, co
     const size_t smem = p.smem + (stat_part ? p.stat_smem : 0);
     constexpr int kMaxSmem = 2 * kStg * 256 * 16 + 4 * 8 * 16 * 2 * 8;   // two halo buffers + float64 statistics of up to 128 channels
     MRI3D_REQUIRE(smem <= (size_t)kMaxSmem, MRI3D_ENOTSUP, "conv3d(mfma): too many output channels for fused statistics");
+    // forward: the split is on the input (K) side; data gradient: on the output (N) side
+    const void* x2 = dgrad ? nullptr : sp.second;
+    void* y2 = dgrad ? const_cast<void*>(sp.second) : nullptr;
+    const int x2_ld = dgrad ? 0 : sp.second_ld, ksplit = dgrad ? 0 : sp.split, y2_ld = dgrad ? sp.second_ld : 0, nsplit = dgrad ? sp.split : 0;
 #define MRI3D_FWD2_CASE(NTv, STv, N8v)                                                                                \
     if (p.NT == NTv && (stat_part != nullptr) == STv && n8 == N8v) {                                                  \
         auto kern = conv_mfma_fwd2_kernel<T, NTv, STv, N8v>;                                                          \
@@ -996,7 +1019,7 @@ static int run_mfma_fwd(const Mri3dConvGeom& g, bool dgrad, const void* in_v, co
         (void)attr;   /* once per kernel, not per launch */                                                          \
         hipLaunchKernelGGL(kern, dim3(p.grid), dim3(256), smem, s, (const T*)in_v, wp, bias, (T*)out_v, g.n, g.di,    \
                            g.hi, g.wi, Kc, in_ld, Nc, out_ld, p.NTT, p.gy, p.tilesD, p.tilesH, p.tilesW, st,         \
-                           stat_part);                                                                                \
+                           stat_part, (const T*)x2, x2_ld, ksplit, (T*)y2, y2_ld, nsplit);                           \
     }
     MRI3D_DISPATCH_DTYPE(g.dtype, T, {
         MRI3D_FWD2_CASE(1, false, false)
@@ -1030,6 +1053,19 @@ int conv_mfma_fwd_stats(const Mri3dConvGeom& g, const void* x, const float* w, c
 int conv_mfma_dgrad(const Mri3dConvGeom& g, const void* dy, const float* w, const float* bias, void* dx, void* ws,
                     size_t ws_bytes, hipStream_t s) {
     return run_mfma_fwd(g, true, dy, w, bias, dx, ws, ws_bytes, s);
+}
+
+// ---- split operands (conv over cat((x, x2), channels)): served by the tiled forward kernel and the transposed-tile weight
+// gradient kernels only; `split` and the second tensor's channel count must be multiples of 16 (bf16 weight gradient: 8 for the
+// second), the second tensor 16-byte aligned with a pitch like the first's
+int conv_mfma_fwd_cat(const Mri3dConvGeom& g, const void* x, const void* x2, int split, int x2_ld, const float* w, const float* bias,
+                      void* y, double* stat_part, void* ws, size_t ws_bytes, hipStream_t s) {
+    return run_mfma_fwd(g, false, x, w, bias, y, ws, ws_bytes, s, stat_part, ConvSplit{x2, split, x2_ld});
+}
+
+int conv_mfma_dgrad_cat(const Mri3dConvGeom& g, const void* dy, const float* w, void* dx, void* dx2, int split, int dx2_ld, void* ws,
+                        size_t ws_bytes, hipStream_t s) {
+    return run_mfma_fwd(g, true, dy, w, nullptr, dx, ws, ws_bytes, s, nullptr, ConvSplit{dx2, split, dx2_ld});
 }
 
 // ================================================================== weight gradient
@@ -1589,8 +1625,14 @@ template <bool BIAS>
 __global__ void __launch_bounds__(256, 2)
 conv_mfma_wgrad_bf16_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ dy, float* __restrict__ part, int N,
                             int D, int H, int W, int Ci, int x_ld, int Co, int y_ld, int tilesD, int tilesH, int tilesW,
-                            int ntiles) {
+                            int ntiles, const bf16_t* __restrict__ x2, int x2_ld, int ksplit) {
     constexpr int TG = 27, TGA = TG + (BIAS ? 1 : 0);
+    // conv over cat((x, x2)): this workgroup's 16-channel ci-tile lives in ONE of the two tensors — rebind x / pitch / channel origin
+    int xc0 = (int)blockIdx.y * 16, xcn = Ci;   // first channel of the tile inside its tensor, channels of that tensor
+    if (x2 != nullptr) {
+        if (xc0 >= ksplit) { x = x2; x_ld = x2_ld; xc0 -= ksplit; xcn = Ci - ksplit; }
+        else xcn = ksplit;
+    }
     extern __shared__ __attribute__((aligned(16))) float lds[];
     char* xs = reinterpret_cast<char*>(lds);
     char* ys = xs + BXS;
@@ -1633,7 +1675,7 @@ conv_mfma_wgrad_bf16_kernel(const bf16_t* __restrict__ x, const bf16_t* __restri
     const unsigned xrel = (unsigned)((((s_row / BHH) * H + s_row % BHH) * W + 8 * s_wg) * x_ld + 8 * s_half);
     const unsigned yrel = (unsigned)((((s_row / BTH) * H + s_row % BTH) * W + 8 * s_wg) * y_ld + 8 * s_half);
     const unsigned hrel = (unsigned)((((hy_row / BTH) * H + hy_row % BTH) * W + (h_side ? BTW + 1 : 0)) * y_ld + 8 * h_half);
-    const bool ch_full = cit * 16 + 16 <= Ci && cob * 16 + 16 <= Co;
+    const bool ch_full = xc0 + 16 <= xcn && cob * 16 + 16 <= Co;
     auto load_tile = [&](int tile) {
         const int w0 = (tile % tilesW) * BTW;
         tile /= tilesW;
@@ -1643,7 +1685,7 @@ conv_mfma_wgrad_bf16_kernel(const bf16_t* __restrict__ x, const bf16_t* __restri
         const int n = tile / tilesH;
         if (d0 >= 1 && d0 + BTD < D && h0 >= 1 && h0 + BTH < H && w0 >= 1 && w0 + BTW < W && ch_full) {
             // interior tile (wave-uniform): scalar bases + precomputed lane offsets, no coordinates, no masks
-            const bf16_t* xb = x + ((((int64_t)n * D + d0 - 1) * H + h0 - 1) * W + w0) * x_ld + cit * 16;
+            const bf16_t* xb = x + ((((int64_t)n * D + d0 - 1) * H + h0 - 1) * W + w0) * x_ld + xc0;
             const bf16_t* yb = dy + ((((int64_t)n * D + d0) * H + h0) * W + w0) * y_ld + cob * 16;
 #pragma unroll
             for (int j = 0; j < 8; ++j) vx[j] = ldg4u(xb + j * x_ld + xrel);
@@ -1656,9 +1698,9 @@ conv_mfma_wgrad_bf16_kernel(const bf16_t* __restrict__ x, const bf16_t* __restri
         }
         {   // ---- X: 8 voxels x 8 channels per lane
             const int gd = d0 - 1 + s_row / BHH, gh = h0 - 1 + s_row % BHH;
-            const int c0 = cit * 16 + 8 * s_half;
-            const bool rok = (unsigned)gd < (unsigned)D && (unsigned)gh < (unsigned)H && c0 < Ci;
-            const bf16_t* src = x + ((((int64_t)n * D + (rok ? gd : 0)) * H + (rok ? gh : 0)) * W) * x_ld + (c0 < Ci ? c0 : 0);
+            const int c0 = xc0 + 8 * s_half;
+            const bool rok = (unsigned)gd < (unsigned)D && (unsigned)gh < (unsigned)H && c0 < xcn;
+            const bf16_t* src = x + ((((int64_t)n * D + (rok ? gd : 0)) * H + (rok ? gh : 0)) * W) * x_ld + (c0 < xcn ? c0 : 0);
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 const int gw = w0 + 8 * s_wg + j;
@@ -1788,8 +1830,12 @@ __device__ __forceinline__ float4 ldg4(const float* p) {
 template <bool BIAS>
 __global__ void __launch_bounds__(256, 2)
 conv_mfma_wgrad6_kernel(const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ part, int N, int D,
-                        int H, int W, int Ci, int x_ld, int Co, int y_ld, int tilesD, int tilesH, int tilesW, int ntiles) {
+                        int H, int W, int Ci, int x_ld, int Co, int y_ld, int tilesD, int tilesH, int tilesW, int ntiles,
+                        const float* __restrict__ x2, int x2_ld, int ksplit) {
     constexpr int TG = 27, TGA = TG + (BIAS ? 1 : 0);
+    // conv over cat((x, x2)): this workgroup's 16-channel ci-tile lives in ONE of the two tensors — rebind x / pitch / channel origin
+    int xc0 = (int)blockIdx.y * 16;
+    if (x2 != nullptr && xc0 >= ksplit) { x = x2; x_ld = x2_ld; xc0 -= ksplit; }
     extern __shared__ __attribute__((aligned(16))) float lds[];
     char* xs = reinterpret_cast<char*>(lds);
     char* ys = xs + BXS;
@@ -1842,7 +1888,7 @@ conv_mfma_wgrad6_kernel(const float* __restrict__ x, const float* __restrict__ d
         const int h0 = (tile % tilesH) * BTH;
         const int n = tile / tilesH;
         // wave-uniform bases; the X base may point before the tensor (d0 = 0 ...) and is only dereferenced at valid offsets
-        const float* xb = x + ((((int64_t)n * D + d0 - 1) * H + h0 - 1) * W + w0) * x_ld + cit * 16;
+        const float* xb = x + ((((int64_t)n * D + d0 - 1) * H + h0 - 1) * W + w0) * x_ld + xc0;
         const int c0 = cob * 16 + 4 * s_q;
         const float* yb = dy + ((((int64_t)n * D + d0) * H + h0) * W + w0) * y_ld + cob * 16;
         // Interior tile (the common case; wave-uniform test on scalars): every piece is in the volume, so a piece's address is
@@ -2082,6 +2128,18 @@ static bool mfma_wgrad_plan(const Mri3dConvGeom& g, MfmaWgradPlan& p) {
     return true;
 }
 
+bool conv_mfma_cat_supported(const Mri3dConvGeom& g, int split, int second_ld, int pass) {
+    const bool bf = g.dtype == MRI3D_BF16;
+    if (split <= 0 || split >= g.ci || split % 16 != 0 || second_ld % (bf ? 8 : 4) != 0 || second_ld < g.ci - split) return false;
+    if (direct_only(g)) return false;
+    MfmaFwdPlan p;
+    MfmaWgradPlan q;
+    if (pass == MRI3D_PASS_FWD) return mfma_fwd_plan(g, false, p) && !p.small && (g.ci - split) % 8 == 0;
+    if (pass == MRI3D_PASS_DGRAD) return mfma_fwd_plan(g, true, p) && !p.small && (g.ci - split) % 4 == 0;   // N side: 16-channel tiles
+    if (pass == MRI3D_PASS_WGRAD) return mfma_wgrad_plan(g, q) && (q.v2 == 4 ? (g.ci - split) % 16 == 0 : q.v2 == 3);
+    return false;
+}
+
 bool conv_mfma_supported(const Mri3dConvGeom& g, int pass) {
     MfmaFwdPlan p;
     MfmaWgradPlan q;
@@ -2127,7 +2185,7 @@ static void launch_mfma_wgrad_cin1(const MfmaWgradPlan& p, const Mri3dConvGeom& 
 
 template <typename T>
 static void run_mfma_wgrad(const MfmaWgradPlan& p, const Mri3dConvGeom& g, const T* x, const T* dy, float* part, bool bias,
-                           hipStream_t s) {
+                           hipStream_t s, ConvSplit sp = ConvSplit{nullptr, 0, 0}) {
     // the kernel template reserves the bias accumulator slot in the partial layout (TGA = TG + 1) only when BIAS
     if (p.v2 == 3) {
         if constexpr (sizeof(T) == 2) {
@@ -2137,7 +2195,8 @@ static void run_mfma_wgrad(const MfmaWgradPlan& p, const Mri3dConvGeom& g, const
         auto kern = conv_mfma_wgrad_bf16_kernel<Bv>;                                                                  \
         MRI3D_SET_SMEM_ONCE(kern, p.smem);                                                                            \
         hipLaunchKernelGGL(kern, grid, dim3(256), p.smem, s, x, dy, part, g.n, g.di, g.hi, g.wi, g.ci, g.x_ld, g.co,  \
-                           g.y_ld, p.tilesD, p.tilesH, p.tilesW, p.ntiles);                                           \
+                           g.y_ld, p.tilesD, p.tilesH, p.tilesW, p.ntiles, (const bf16_t*)sp.second, sp.second_ld,    \
+                           sp.split);                                                                                 \
     }
             if (bias) MRI3D_WGB(true) else MRI3D_WGB(false)
 #undef MRI3D_WGB
@@ -2150,7 +2209,8 @@ static void run_mfma_wgrad(const MfmaWgradPlan& p, const Mri3dConvGeom& g, const
         auto kern = conv_mfma_wgrad6_kernel<Bv>;                                                                      \
         MRI3D_SET_SMEM_ONCE(kern, p.smem);                                                                            \
         hipLaunchKernelGGL(kern, grid, dim3(256), p.smem, s, x, dy, part, g.n, g.di, g.hi, g.wi, g.ci, g.x_ld, g.co,  \
-                           g.y_ld, p.tilesD, p.tilesH, p.tilesW, p.ntiles);                                           \
+                           g.y_ld, p.tilesD, p.tilesH, p.tilesW, p.ntiles, (const float*)sp.second, sp.second_ld,     \
+                           sp.split);                                                                                 \
     }
             if (bias) MRI3D_WG6(true) else MRI3D_WG6(false)
 #undef MRI3D_WG6
@@ -2185,8 +2245,21 @@ static void run_mfma_wgrad(const MfmaWgradPlan& p, const Mri3dConvGeom& g, const
     }
 }
 
+static int run_wgrad(const Mri3dConvGeom& g, const void* x, const void* dy, float* dw, float* dbias, void* ws, size_t ws_bytes,
+                     hipStream_t s, ConvSplit sp);
+
 int conv_mfma_wgrad(const Mri3dConvGeom& g, const void* x, const void* dy, float* dw, float* dbias, void* ws,
                     size_t ws_bytes, hipStream_t s) {
+    return run_wgrad(g, x, dy, dw, dbias, ws, ws_bytes, s, ConvSplit{nullptr, 0, 0});
+}
+
+int conv_mfma_wgrad_cat(const Mri3dConvGeom& g, const void* x, const void* x2, int split, int x2_ld, const void* dy, float* dw,
+                        float* dbias, void* ws, size_t ws_bytes, hipStream_t s) {
+    return run_wgrad(g, x, dy, dw, dbias, ws, ws_bytes, s, ConvSplit{x2, split, x2_ld});
+}
+
+static int run_wgrad(const Mri3dConvGeom& g, const void* x, const void* dy, float* dw, float* dbias, void* ws, size_t ws_bytes,
+                     hipStream_t s, ConvSplit sp) {
     MfmaWgradPlan p;
     MRI3D_REQUIRE(mfma_wgrad_plan(g, p), MRI3D_ENOTSUP, "conv3d_wgrad(mfma): unsupported geometry");
     MRI3D_REQUIRE(ws && ws_bytes >= p.part_floats * sizeof(float), MRI3D_EWORKSPACE,
@@ -2196,7 +2269,8 @@ int conv_mfma_wgrad(const Mri3dConvGeom& g, const void* x, const void* dy, float
                   "conv3d_wgrad(bf16 mfma): x/dy must be 16-byte aligned");
     float* part = static_cast<float*>(ws);
     const bool bias = dbias != nullptr;
-    MRI3D_DISPATCH_DTYPE(g.dtype, T, { run_mfma_wgrad<T>(p, g, static_cast<const T*>(x), static_cast<const T*>(dy), part, bias, s); });
+    MRI3D_REQUIRE(sp.second == nullptr || p.v2 == 3 || p.v2 == 4, MRI3D_ENOTSUP, "conv3d_wgrad(mfma): split operands need the transposed-tile kernels");
+    MRI3D_DISPATCH_DTYPE(g.dtype, T, { run_mfma_wgrad<T>(p, g, static_cast<const T*>(x), static_cast<const T*>(dy), part, bias, s, sp); });
     const int TGA = p.TG + (bias ? 1 : 0);
     const int nelem = p.CIT * p.COB * TGA * 256;
     hipLaunchKernelGGL(wgrad_mfma_reduce_kernel, dim3(cdiv(nelem, 64)), dim3(256), 0, s, part, dw, dbias, p.P, p.CIT,

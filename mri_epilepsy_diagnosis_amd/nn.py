@@ -77,7 +77,16 @@ def conv_norm_act(conv, norm, act, x, out=None):
     wants = (isinstance(norm, tnn.modules.batchnorm._BatchNorm) and (norm.training or norm.running_mean is None)
              and ops.sync_batchnorm_reducer() is None and isinstance(conv, Conv3d) and conv.padding_mode == "zeros"
              and conv.groups == 1 and not isinstance(conv.padding, str))
-    if wants:
+    if isinstance(x, (tuple, list)):
+        # x = (xa, xb): the convolution of torch.cat((xa, xb), dim=1), read from the two tensors (ops.conv3d_cat)
+        xa, xb = x
+        plain = (isinstance(conv, Conv3d) and conv.padding_mode == "zeros" and conv.groups == 1 and not isinstance(conv.padding, str)
+                 and tuple(conv.stride) == (1, 1, 1) and tuple(conv.dilation) == (1, 1, 1))
+        if plain:
+            y = ops.conv3d_cat(xa, xb, conv.weight, conv.bias, conv.padding, bn_stats=wants)
+        else:
+            y = conv(ops.cat_channels([xa, xb]))
+    elif wants:
         y = ops.conv3d(x, conv.weight, conv.bias, conv.stride, conv.padding, conv.dilation, bn_stats=True)
     else:
         y = conv(x)

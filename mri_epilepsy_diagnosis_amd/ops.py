@@ -485,6 +485,99 @@ class _Conv3dFn(torch.autograd.Function):
         return dx, dw, db, None, None, None, None
 
 
+class _Conv3dCatFn(torch.autograd.Function):
+    """conv3d(torch.cat((xa, xb), dim=1), w, b, padding=1) for a 3x3x3 kernel WITHOUT the concatenation: the MFMA kernels read the
+    two tensors chunk by chunk (mri3d_conv3d_fwd_cat / _wgrad_cat) and the data gradient comes out as two dense tensors
+    (mri3d_conv3d_dgrad_cat).  unet.UNet decoder: cat((skip, upsampled)) -> ConvolutionalBlock (segmentation/routine.py:346-356).
+    Writing a 16-channel slice of a 48-channel NDHWC buffer costs 1.5x (fp32) to 3.6x (bf16) of a dense write
+    (tools/slice_write_probe.py), which is what the copy-free concat buffer of round 1 made its producers do."""
+
+    @staticmethod
+    def forward(ctx, xa, xb, weight, bias, stats_holder=None):
+        _require_device(xa, xb)
+        _require_param(weight, bias)
+        L = _lib.lib()
+        xa, a_ld = _nd(xa)
+        xb, b_ld = _nd(xb)
+        w = weight.contiguous()
+        ca, cb = xa.shape[1], xb.shape[1]
+        g = _conv_geom((xa.shape[0], ca + cb) + tuple(xa.shape[2:]), w.shape, (1, 1, 1), (1, 1, 1), (1, 1, 1), x_ld=a_ld, dtype=_dt(xa))
+        y = _new((g.n, g.co, g.dout, g.ho, g.wo), xa)
+        ws = _workspace(L.mri3d_conv3d_workspace_bytes(ctypes.byref(g), PASS_FWD), xa.device)
+        part = None
+        if stats_holder is not None:
+            gq = _conv_geom((xa.shape[0], ca + cb) + tuple(xa.shape[2:]), w.shape, (1, 1, 1), (1, 1, 1), (1, 1, 1), dtype=_dt(xa))
+            blocks = L.mri3d_conv3d_fwd_stats_blocks(ctypes.byref(gq))     # (a query about the concatenated geometry)
+            if blocks > 0:
+                part = torch.empty(blocks * g.co * 2, dtype=torch.float64, device=xa.device)
+                stats_holder.append((part, blocks, bias.detach() if bias is not None else None))
+        with _timed(lambda: _conv_tag("fwd", g) + " cat" + (" +bn-stats" if part is not None else ""), lambda: _conv_work(g, "fwd")):
+            check(L.mri3d_conv3d_fwd_cat(ctypes.byref(g), _ptr(xa), _ptr(xb), ca, b_ld, _ptr(w), _ptr(bias), _ptr(y), _ptr(part),
+                                         _ptr(ws), ws.numel(), _stream()), "conv3d_fwd_cat")
+        ctx.save_for_backward(xa, xb, w)
+        ctx.geom, ctx.b_ld, ctx.has_bias, ctx.params = g, b_ld, bias is not None, (weight, bias)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        xa, xb, w = ctx.saved_tensors
+        g, L = ctx.geom, _lib.lib()
+        dy, y_ld = _nd(dy)
+        ca, cb = xa.shape[1], xb.shape[1]
+        dxa = dxb = dw = db = None
+        if ctx.needs_input_grad[0] or ctx.needs_input_grad[1]:
+            gd = _conv_geom((g.n, g.ci, g.di, g.hi, g.wi), w.shape, (1, 1, 1), (1, 1, 1), (1, 1, 1), x_ld=ca, y_ld=y_ld, dtype=g.dtype)
+            dxa, dxb = _new(xa.shape, xa), _new(xb.shape, xb)      # two dense tensors
+            ws = _workspace(L.mri3d_conv3d_workspace_bytes(ctypes.byref(gd), PASS_DGRAD), dy.device)
+            with _timed(lambda: _conv_tag("dgrad", gd) + " cat", lambda: _conv_work(gd, "dgrad")):
+                check(L.mri3d_conv3d_dgrad_cat(ctypes.byref(gd), _ptr(dy), _ptr(w), _ptr(dxa), _ptr(dxb), ca, cb, _ptr(ws),
+                                               ws.numel(), _stream()), "conv3d_dgrad_cat")
+        if ctx.needs_input_grad[2] or (ctx.has_bias and ctx.needs_input_grad[3]):
+            gw = _conv_geom((g.n, g.ci, g.di, g.hi, g.wi), w.shape, (1, 1, 1), (1, 1, 1), (1, 1, 1), x_ld=g.x_ld, y_ld=y_ld, dtype=g.dtype)
+            wp, bp = ctx.params
+            want_b = ctx.has_bias and ctx.needs_input_grad[3]
+            dw_out = _sink_take(wp) if ctx.needs_input_grad[2] else None
+            db_out = _sink_take(bp) if want_b else None
+            dw = dw_out if dw_out is not None else torch.empty_like(w, memory_format=torch.contiguous_format)
+            db = (db_out if db_out is not None else torch.empty(g.co, dtype=w.dtype, device=w.device)) if ctx.has_bias else None
+            ws = _workspace(L.mri3d_conv3d_workspace_bytes(ctypes.byref(gw), PASS_WGRAD), dy.device)
+            with _timed(lambda: _conv_tag("wgrad", gw) + " cat", lambda: _conv_work(gw, "wgrad")):
+                check(L.mri3d_conv3d_wgrad_cat(ctypes.byref(gw), _ptr(xa), _ptr(xb), ca, ctx.b_ld, _ptr(dy), _ptr(dw), _ptr(db), _ptr(ws),
+                                               ws.numel(), _stream()), "conv3d_wgrad_cat")
+            dw = _sink_done(wp, dw, dw_out) if ctx.needs_input_grad[2] else None
+            db = _sink_done(bp, db, db_out) if want_b else None
+        return dxa, dxb, dw, db, None
+
+
+def conv3d_cat(xa, xb, weight, bias=None, padding=1, bn_stats=False):
+    """conv3d(torch.cat((xa, xb), dim=1), weight, bias, padding=padding) — without the concatenation where the MFMA kernels serve all
+    three passes of the geometry (3x3x3 / stride 1 / pad 1, channel counts in multiples of 16), with an explicit one otherwise."""
+    if _autocast_dtype is not None:
+        xa = convert(xa, _autocast_dtype) if xa.dtype != _autocast_dtype else xa
+        xb = convert(xb, _autocast_dtype) if xb.dtype != _autocast_dtype else xb
+    ok = (xa.is_cuda and xa.dim() == 5 and xb.shape[0] == xa.shape[0] and xb.shape[2:] == xa.shape[2:] and xa.dtype == xb.dtype
+          and tuple(weight.shape[2:]) == (3, 3, 3) and _triple(padding) == (1, 1, 1) and weight.shape[1] == xa.shape[1] + xb.shape[1])
+    if ok:
+        L = _lib.lib()
+        a_nd, a_ld = _nd(xa)
+        b_nd, b_ld = _nd(xb)
+        ca, cb = xa.shape[1], xb.shape[1]
+        shape = (xa.shape[0], ca + cb) + tuple(xa.shape[2:])
+        gf = _conv_geom(shape, weight.shape, (1, 1, 1), (1, 1, 1), (1, 1, 1), x_ld=a_ld, dtype=_dt(a_nd))
+        gd = _conv_geom(shape, weight.shape, (1, 1, 1), (1, 1, 1), (1, 1, 1), x_ld=ca, dtype=_dt(a_nd))
+        ok = (a_nd.data_ptr() % 16 == 0 and b_nd.data_ptr() % 16 == 0
+              and L.mri3d_conv3d_cat_supported(ctypes.byref(gf), ca, b_ld, PASS_FWD)
+              and L.mri3d_conv3d_cat_supported(ctypes.byref(gf), ca, b_ld, PASS_WGRAD)
+              and L.mri3d_conv3d_cat_supported(ctypes.byref(gd), ca, cb, PASS_DGRAD))
+    if not ok:
+        return conv3d(cat_channels([xa, xb]), weight, bias, 1, padding, 1, bn_stats=bn_stats)
+    holder = [] if bn_stats else None
+    y = _Conv3dCatFn.apply(xa, xb, weight, bias, holder)
+    if holder:
+        y._mri3d_bn_stats = holder[0]
+    return y
+
+
 def conv3d(x, weight, bias=None, stride=1, padding=0, dilation=1, bn_stats=False):
     """bn_stats=True: the caller applies a batch-statistics BatchNorm to the result next (nn.conv_norm_act); where the MFMA
     forward kernel serves the geometry its epilogue accumulates the statistics, and `norm_act` picks them up from the result."""

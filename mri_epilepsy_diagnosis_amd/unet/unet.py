@@ -128,17 +128,17 @@ class DecodingBlock(tnn.Module):
 
     def forward(self, skip, x, cat_buf=None):
         if cat_buf is not None and isinstance(self.upsample, mnn.Upsample):
-            # copy-free torch.cat((skip, up)): `skip` already lives in cat_buf[:, :Cs]; the upsample kernel writes
-            # cat_buf[:, Cs:]; join_channels only ties the two producers together for autograd (skip first: SURVEY A.3)
+            # copy-free torch.cat((skip, up)) through a shared buffer: `skip` already lives in cat_buf[:, :Cs]; the upsample kernel
+            # writes cat_buf[:, Cs:]; join_channels only ties the two producers together for autograd (skip first: SURVEY A.3)
             up = ops.upsample3d(x, self.upsample.size, self.upsample.scale_factor, self.upsample.mode,
                                 self.upsample.align_corners, out=(cat_buf, skip.shape[1]))
-            x = ops.join_channels(cat_buf, [skip, up])
-        else:
-            x = self.upsample(x)
-            if skip.shape[2:] != x.shape[2:]:
-                raise NotImplementedError("padding=False (centre-cropped skips) is not used by the reference")
-            x = ops.cat_channels([skip, x])
-        return self.conv2(self.conv1(x))
+            return self.conv2(self.conv1(ops.join_channels(cat_buf, [skip, up])))
+        x = self.upsample(x)
+        if skip.shape[2:] != x.shape[2:]:
+            raise NotImplementedError("padding=False (centre-cropped skips) is not used by the reference")
+        # cat((skip, x)) is never formed: the first convolution reads the two dense tensors (ops.conv3d_cat) and hands back two
+        # dense gradients.  Slice writes into a shared 3C-channel buffer cost 1.5x (fp32) - 3.6x (bf16) of dense writes.
+        return self.conv2(self.conv1((skip, x)))
 
 
 class Decoder(tnn.Module):
@@ -185,13 +185,15 @@ class UNet(tnn.Module):
         self.decoder = Decoder(skip_channels, dimensions, upsampling_type, depth, normalization, padding=padding,
                                activation=activation, initial_dilation=self.encoder.dilation)
         self.monte_carlo_layer = None
+        self.shared_concat_buffers = False   # round 1's concat-buffer scheme (A/B switch; not part of the reference's API)
         self.classifier = ConvolutionalBlock(dimensions, 2 * out_channels_first_layer, out_classes, kernel_size=1,
                                              activation=None)
 
     def forward(self, x):
-        # One NDHWC buffer per level holds cat((skip, upsampled)); both producers write their channel slice in place.
+        # Round 1's scheme (kept for A/B: set `shared_concat_buffers`): one NDHWC buffer per level holds cat((skip, upsampled)) and
+        # both producers write their channel slice in place.  Default since round 2: no concatenation at all (DecodingBlock.forward).
         cat_bufs = None
-        if x.is_cuda and len(self.encoder.encoding_blocks) and all(
+        if self.shared_concat_buffers and x.is_cuda and len(self.encoder.encoding_blocks) and all(
                 isinstance(b.upsample, mnn.Upsample) for b in self.decoder.decoding_blocks):
             cat_bufs = []
             n, sp = x.shape[0], tuple(x.shape[2:])

@@ -555,3 +555,56 @@ def test_max_pool3d_2_nan_and_index_semantics_equal_torch(dtype):
     a, r = to_ncdhw(yd).float().cpu(), yr.detach()
     assert torch.equal(torch.isnan(a), torch.isnan(r)) and torch.equal(a[~torch.isnan(r)], r[~torch.isnan(r)])
     assert torch.equal(to_ncdhw(xd.grad).float().cpu(), xr.grad)
+
+
+# (batch, Ca, Cb, Cout, volume, channel padding of the second tensor's buffer, bias, served by the split kernels in fp32 / bf16)
+CAT_CASES = [(2, 16, 32, 16, (24, 40, 70), 0, True, True, True), (2, 32, 64, 32, (21, 33, 70), 8, True, True, True),
+             (3, 16, 16, 8, (17, 40, 65), 0, False, True, True),
+             (2, 16, 24, 16, (24, 40, 70), 0, True, False, True),      # 24 trailing channels: not a ci-tile multiple for the fp32 weight gradient
+             (1, 8, 16, 16, (24, 40, 70), 0, True, False, False),      # 8 leading channels: the split must be a multiple of 16
+             (1, 16, 32, 16, (6, 7, 9), 0, True, False, True)]         # tiny volume: fp32 runs on the LDS-free kernel (no split support)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
+@pytest.mark.parametrize("case", CAT_CASES, ids=lambda c: "n%d_%d+%d-%d_%s_p%d_b%d" % (c[0], c[1], c[2], c[3], "x".join(map(str, c[4])), c[5], c[6]))
+def test_conv3d_cat_equals_conv_of_the_concatenation(case, dtype):
+    """ops.conv3d_cat(xa, xb, w) — the U-Net decoder's conv over cat((skip, upsampled)) read from the two tensors — against
+    ops.conv3d on the explicit concatenation: same kernels, same summation order, so outputs, both input gradients, weight and bias
+    gradients are BIT-identical; with the second tensor as a pitched channel slice; with fused BatchNorm statistics; and on shapes
+    the split kernels do not serve (8 leading channels, tiny volume, 24 trailing channels in fp32), where it must fall back to
+    the concatenation."""
+    nb, ca, cb, co, sp, pad_b, has_bias, served_f32, served_bf16 = case
+    served = served_f32 if dtype == torch.float32 else served_bf16
+    g = torch.Generator().manual_seed(ca * 100 + cb)
+    xa = torch.randn(nb, ca, *sp, generator=g).cuda().to(dtype).contiguous(memory_format=torch.channels_last_3d)
+    bbuf = torch.zeros(nb, cb + pad_b, *sp, device="cuda", dtype=dtype).contiguous(memory_format=torch.channels_last_3d)
+    bbuf[:, pad_b:] = torch.randn(nb, cb, *sp, generator=g).cuda().to(dtype)
+    wt = (torch.randn(co, ca + cb, 3, 3, 3, generator=g) / np.sqrt(27 * (ca + cb))).cuda()
+    b = torch.randn(co, generator=g).cuda() if has_bias else None
+    dy = torch.randn(nb, co, *sp, generator=g).cuda().to(dtype).contiguous(memory_format=torch.channels_last_3d)
+    res = []
+    for split in (False, True):
+        a = xa.clone().requires_grad_(True)
+        bb = bbuf[:, pad_b:].detach().requires_grad_(True) if split else bbuf[:, pad_b:].clone().requires_grad_(True)
+        w, bs = wt.clone().requires_grad_(True), (b.clone().requires_grad_(True) if has_bias else None)
+        for stats in (False, True):
+            if split:
+                y = ops.conv3d_cat(a, bb, w, bs, padding=1, bn_stats=stats)
+                assert ("Conv3dCatFn" in type(y.grad_fn).__name__) == served, (type(y.grad_fn).__name__, served)
+            else:
+                y = ops.conv3d(torch.cat((a, bb), dim=1).contiguous(memory_format=torch.channels_last_3d), w, bs, padding=1, bn_stats=stats)
+            if stats:
+                st = getattr(y, "_mri3d_bn_stats", None)
+                res.append((y.detach().clone(), None if st is None else st[0].view(st[1], -1).sum(0).clone()))
+        y.backward(dy)
+        res.append((a.grad, bb.grad, w.grad, None if bs is None else bs.grad))
+    (y0, s0), g0, (y1, s1), g1 = res
+    assert torch.equal(y0, y1)
+    assert (s0 is None) == (s1 is None) and (s0 is None or torch.allclose(s0, s1, rtol=1e-12, atol=0))
+    for name, p, q in zip(("dxa", "dxb", "dw", "db"), g0, g1):
+        assert (p is None) == (q is None)
+        if p is not None:
+            if name in ("dxa", "dxb"):
+                assert torch.equal(p, q), name
+            else:   # the ci-tile -> workgroup map is the same, so is the order of the sums
+                assert torch.equal(p, q), name
