@@ -252,24 +252,25 @@ def main():
         # step's FLOPs) back to back between two events on the launch stream instead.
         conv = model.decoder.decoding_blocks[-1].conv1.conv_layer
         act_dt = torch.bfloat16 if bf16 else torch.float32
-        xs_ = torch.randn(PER_GPU_BATCH, conv.in_channels, *SHAPE, device=device).to(act_dt).contiguous(
-            memory_format=torch.channels_last_3d)
-        dys_ = torch.randn(PER_GPU_BATCH, conv.out_channels, *SHAPE, device=device).to(act_dt).contiguous(
-            memory_format=torch.channels_last_3d)
-        geom = ops._conv_geom(xs_.shape, conv.weight.shape, (1, 1, 1), (1, 1, 1), (1, 1, 1), dtype=ops._dt(xs_))
-        passes = {"fwd": lambda: ops._conv_fwd(geom, xs_, conv.weight.detach(), conv.bias.detach()),
-                  "dgrad": lambda: ops._conv_dgrad(geom, dys_, conv.weight.detach(), None, xs_),
-                  "wgrad": lambda: ops._conv_wgrad(geom, xs_, dys_, conv.weight.detach(), True)}
+        c_skip = conv.in_channels // 3        # cat((skip, upsampled)): C + 2C channels, read from two dense tensors (ops.conv3d_cat)
+        CL = torch.channels_last_3d
+        xs_ = torch.randn(PER_GPU_BATCH, c_skip, *SHAPE, device=device).to(act_dt).contiguous(memory_format=CL).requires_grad_(True)
+        xu_ = torch.randn(PER_GPU_BATCH, conv.in_channels - c_skip, *SHAPE, device=device).to(act_dt).contiguous(memory_format=CL).requires_grad_(True)
+        dys_ = torch.randn(PER_GPU_BATCH, conv.out_channels, *SHAPE, device=device).to(act_dt).contiguous(memory_format=CL)
+        wq_, bq_ = conv.weight.detach().clone().requires_grad_(True), conv.bias.detach().clone().requires_grad_(True)
+
+        def layer_passes():
+            ops.conv3d_cat(xs_, xu_, wq_, bq_, padding=1).backward(dys_)
+
         probe_steps = 5
-        for kind, fn in passes.items():
-            fn()
-            torch.cuda.synchronize()
-            ops.set_timer(timer)
-            for _ in range(probe_steps):
-                fn()
-            ops.set_timer(None)
+        layer_passes()
         torch.cuda.synchronize()
-        del xs_, dys_
+        ops.set_timer(timer)
+        for _ in range(probe_steps):
+            layer_passes()
+        ops.set_timer(None)
+        torch.cuda.synchronize()
+        del xs_, xu_, dys_
     if world > 1:
         tt = torch.tensor([elapsed], device=device, dtype=torch.float64)
         torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)

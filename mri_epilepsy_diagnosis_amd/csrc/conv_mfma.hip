@@ -315,13 +315,13 @@ conv_mfma_fwd2_kernel(const T* __restrict__ x, const float* __restrict__ wp, con
     auto stage_piece = [&](const Item& it, const Stage& st, int j) {   // wave-uniform branches only
         if (!st.on) return;
         if (st.interior) {
-            lds_dma16(vrel[j] * st.ldb + pieceb, st.rs, st.dst + j * 4096);
+            lds_dma16(__umul24(vrel[j], st.ldb) + pieceb, st.rs, st.dst + j * 4096);   // v_mad_u32_u24: both factors < 2^24
         } else {
             const int r = srel[j];
             const int gd = it.d0 - 1 + (r >> 16), gh = it.h0 - 1 + ((r >> 8) & 0xff), gw = it.w0 - 1 + (r & 0xff);
             const bool ok = (unsigned)gd < (unsigned)D && (unsigned)gh < (unsigned)H && (unsigned)gw < (unsigned)W &&
                             it.ch * CK + PE * (tid & 1) < Kc;
-            lds_dma16(ok ? vrel[j] * st.ldb + pieceb : kDmaOob, st.rs, st.dst + j * 4096);
+            lds_dma16(ok ? __umul24(vrel[j], st.ldb) + pieceb : kDmaOob, st.rs, st.dst + j * 4096);
         }
     };
     // pieces issued in front of tap group tg: kPpt per group, so that a wave's issue slots (~60-180 cycles per piece) are

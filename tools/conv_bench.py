@@ -1,5 +1,7 @@
 """Micro-benchmark of one Conv3d geometry through the C ABI (forward, dgrad, wgrad), for kernel tuning and for
-rocprofv3 --pmc runs:   python tools/conv_bench.py CIN COUT D H W [N] [reps] [passes=fwd,dgrad,wgrad] [f32|bf16]"""
+rocprofv3 --pmc runs:   python tools/conv_bench.py [--lib SO] [--cat SPLIT] CIN COUT D H W [N] [reps] [passes=fwd,dgrad,wgrad] [f32|bf16]
+--cat SPLIT: the convolution over cat((xa, xb)) read from two dense tensors of SPLIT and CIN - SPLIT channels (mri3d_conv3d_*_cat:
+the U-Net decoder's first convolution)."""
 import ctypes
 import os
 import sys
@@ -14,6 +16,11 @@ def main():
     if "--lib" in sys.argv:   # a tuning build (python -m mri_epilepsy_diagnosis_amd.build --variant NAME -D...), tools only
         i = sys.argv.index("--lib")
         _lib.LIB_PATH = os.path.abspath(sys.argv[i + 1])
+        del sys.argv[i:i + 2]
+    split = 0
+    if "--cat" in sys.argv:
+        i = sys.argv.index("--cat")
+        split = int(sys.argv[i + 1])
         del sys.argv[i:i + 2]
     ci, co, d, h, w = (int(a) for a in sys.argv[1:6])
     n = int(sys.argv[6]) if len(sys.argv) > 6 else 2
@@ -31,6 +38,27 @@ def main():
     flops = 2.0 * n * co * ci * 27 * d * h * w
     fns = {"fwd": lambda: ops._conv_fwd(geom, x, wt, b), "dgrad": lambda: ops._conv_dgrad(geom, dy, wt, None, x),
            "wgrad": lambda: ops._conv_wgrad(geom, x, dy, wt, True)}
+    if split:
+        L = _lib.lib()
+        CL = torch.channels_last_3d
+        xa, xb = x[:, :split].contiguous(memory_format=CL), x[:, split:].contiguous(memory_format=CL)
+        del x
+        gf = ops._conv_geom((n, ci, d, h, w), wt.shape, (1, 1, 1), (1, 1, 1), (1, 1, 1), x_ld=split, dtype=ops._dt(xa))
+        for ps, cb in ((ops.PASS_FWD, ci - split), (ops.PASS_DGRAD, ci - split), (ops.PASS_WGRAD, ci - split)):
+            assert L.mri3d_conv3d_cat_supported(ctypes.byref(gf), split, cb, ps), "split geometry not served"
+        y = torch.empty((n, co, d, h, w), device=dev, dtype=dt).contiguous(memory_format=CL)
+        dxa, dxb, dw, db = torch.empty_like(xa), torch.empty_like(xb), torch.empty_like(wt), torch.empty_like(b)
+        ws = {ps: ops._workspace(L.mri3d_conv3d_workspace_bytes(ctypes.byref(gf), ps), dev) for ps in (ops.PASS_FWD, ops.PASS_DGRAD, ops.PASS_WGRAD)}
+        P, st = ops._ptr, ops._stream
+
+        def chk(rc):
+            assert rc == 0, L.mri3d_last_error().decode()
+        fns = {"fwd": lambda: chk(L.mri3d_conv3d_fwd_cat(ctypes.byref(gf), P(xa), P(xb), split, ci - split, P(wt), P(b), P(y), None,
+                                                         P(ws[ops.PASS_FWD]), ws[ops.PASS_FWD].numel(), st())),
+               "dgrad": lambda: chk(L.mri3d_conv3d_dgrad_cat(ctypes.byref(gf), P(dy), P(wt), P(dxa), P(dxb), split, ci - split,
+                                                             P(ws[ops.PASS_DGRAD]), ws[ops.PASS_DGRAD].numel(), st())),
+               "wgrad": lambda: chk(L.mri3d_conv3d_wgrad_cat(ctypes.byref(gf), P(xa), P(xb), split, ci - split, P(dy), P(dw), P(db),
+                                                             P(ws[ops.PASS_WGRAD]), ws[ops.PASS_WGRAD].numel(), st()))}
     for p in passes:
         fn = fns[p]
         fn(); fn()
@@ -42,7 +70,7 @@ def main():
         e1.record()
         torch.cuda.synchronize()
         ms = e0.elapsed_time(e1) / reps
-        print("%-5s %d->%d @%dx%dx%d n%d %s: %.3f ms  %.1f TFLOP/s" % (p, ci, co, d, h, w, n, str(dt)[6:], ms, flops / ms / 1e9),
+        print("%-5s %s->%d @%dx%dx%d n%d %s: %.3f ms  %.1f TFLOP/s" % (p, ("%d+%d" % (split, ci - split)) if split else str(ci), co, d, h, w, n, str(dt)[6:], ms, flops / ms / 1e9),
               flush=True)
 
 

@@ -1,6 +1,7 @@
 #!/bin/bash
 # Round-2 evidence, one gpurun call from the repo root:  gpurun --timeout 1100 -- 'bash tools/profile_round2.sh'
 #   1. rocprofv3 --kernel-trace --stats of bench.py (fp32 headline, bf16) and of the dominant 48->16 layer
+#      (the layer as the U-Net runs it: conv over cat((skip 16, upsampled 32)) read from two dense tensors, conv_bench --cat 16)
 #   2. --pmc passes (FETCH_SIZE, WRITE_SIZE, SQ busy: never combined with trace domains) of the three passes of that layer, both dtypes
 #   3. the plain bench lines (no profiler)
 set -o pipefail
@@ -13,10 +14,10 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $O/bench_f32 -o bench_f3
 echo "bench f32 stats done"
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/bench_bf16 -o bench_bf16 -- python3 bench.py --steps 5 --warmup 2 --dtype bf16 > $O/bench_bf16_under_rocprof.json 2> $O/bench_bf16.err || exit 1
 echo "bench bf16 stats done"
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/conv_48_16 -o conv_48_16 -- python3 tools/conv_bench.py 48 16 160 192 160 2 10 fwd,dgrad,wgrad > $O/conv_48_16.log 2>&1 || exit 1
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/conv_48_16 -o conv_48_16 -- python3 tools/conv_bench.py --cat 16 48 16 160 192 160 2 10 fwd,dgrad,wgrad > $O/conv_48_16.log 2>&1 || exit 1
 echo "conv 48->16 stats done"
-bash tools/pmc_conv.sh r02f_f32_48_16 48 16 160 192 160 2 f32 || exit 1
-bash tools/pmc_conv.sh r02f_bf16_48_16 48 16 160 192 160 2 bf16 || exit 1
+bash tools/pmc_conv.sh r02f_f32_48_16 48 16 160 192 160 2 f32 "fwd dgrad wgrad" 16 || exit 1
+bash tools/pmc_conv.sh r02f_bf16_48_16 48 16 160 192 160 2 bf16 "fwd dgrad wgrad" 16 || exit 1
 cd $R
 python3 bench.py > $O/final_bench_f32.json 2> $O/final_bench_f32_optable.txt || exit 1
 python3 bench.py --dtype bf16 > $O/final_bench_bf16.json 2> $O/final_bench_bf16_optable.txt || exit 1

@@ -12,12 +12,13 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src, out, dt = sys.argv[1], sys.argv[2], (sys.argv[3] if len(sys.argv) > 3 else "f32")
+cat = " cat" if (len(sys.argv) > 4 and sys.argv[4] == "cat") else ""     # the split-operand passes (tools/pmc_conv.sh ... SPLIT)
 d = json.load(open(os.path.join(src, "summary.json")))
 suffix = " bf16" if dt == "bf16" else ""
 rec = {"_note": __doc__.split("\n\n", 1)[1].replace("\n", " "), "_source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), tools/pmc_conv.sh"}
 for key, e in d.items():
     p = key.split()[0]
-    tag = "conv3d_%s 3x3x3 s1 d1 48->16 @160x192x160 n2%s" % (p, suffix)
+    tag = "conv3d_%s 3x3x3 s1 d1 48->16 @160x192x160 n2%s%s" % (p, suffix, cat)
     rec[tag] = {"kernel": e["kernel"], "raw_fetch_size_bytes": e.get("raw_fetch_bytes"), "fetch_bytes": 2.0 * e.get("raw_fetch_bytes", 0.0),
                 "write_bytes": e.get("write_bytes"), "traffic_bytes": 2.0 * e.get("raw_fetch_bytes", 0.0) + e.get("write_bytes", 0.0),
                 "algorithmic_bytes": e["algorithmic_bytes"], "mfma_busy_frac": e.get("mfma_busy_frac")}
