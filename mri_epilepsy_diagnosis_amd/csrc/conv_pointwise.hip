@@ -56,67 +56,84 @@ pw_dgrad_kernel(const T* __restrict__ dy, const float* __restrict__ w, const flo
 constexpr int kPwMaxBlocks = 1024;
 
 // part[blk][co][ci] (+ bias_part[blk][co])
-template <typename T, int CO>
+// VX = input channels per lane: 4 (fp32: 16-byte loads) or 8 (bf16: 16-byte loads; with 4 the bf16 kernel moved 8 bytes per lane
+// plus two 2-byte dy loads per voxel and ran at 1.5 TB/s, slower in absolute time than the fp32 one).  DYV: dy is dense with
+// exactly CO channels, so a voxel's dy is ONE vector load.
+template <typename T, int CO, int VX, bool DYV>
 __global__ void __launch_bounds__(256)
 pw_wgrad_kernel(const T* __restrict__ x, const T* __restrict__ dy, double* __restrict__ part,
                 double* __restrict__ bias_part, int64_t nvox, int Ci, int Co, int x_ld, int y_ld) {
-    extern __shared__ __attribute__((aligned(16))) double redd[];  // [256][4*CO + CO]
-    const int QC = Ci >> 2;
+    extern __shared__ __attribute__((aligned(16))) double redd[];  // [256][VX*CO + CO]
+    const int QC = Ci / VX;
     const int VL = 256 / QC;
     const int tid = threadIdx.x;
     const int q = tid % QC, vl = tid / QC;
-    double acc[4][CO], bsum[CO];
+    double acc[VX][CO], bsum[CO];
 #pragma unroll
     for (int c = 0; c < CO; ++c) {
         bsum[c] = 0.0;
 #pragma unroll
-        for (int a = 0; a < 4; ++a) acc[a][c] = 0.0;
+        for (int a = 0; a < VX; ++a) acc[a][c] = 0.0;
     }
     if (vl < VL) {
         constexpr int U = 4;
         const int64_t stride = (int64_t)gridDim.x * VL;
         for (int64_t v0 = (int64_t)blockIdx.x * VL + vl; v0 < nvox; v0 += stride * U) {
-            float4 xv[U];
+            float xv[U][VX];
             float gv[U][CO];
 #pragma unroll
             for (int u = 0; u < U; ++u) {   // issue all loads of the 4 voxels first
                 const int64_t v = v0 + u * stride;
                 const bool ok = v < nvox;
-                xv[u] = ok ? ldf4(x + v * x_ld + 4 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
+                const T* xp = x + (ok ? v : 0) * x_ld + VX * q;
+                if constexpr (VX == 8) {
+                    const bf16x8_t t = *reinterpret_cast<const bf16x8_t*>(xp);
 #pragma unroll
-                for (int c = 0; c < CO; ++c) gv[u][c] = (ok && c < Co) ? ldf(dy + v * y_ld + c) : 0.f;
+                    for (int a = 0; a < 8; ++a) xv[u][a] = ok ? (float)t[a] : 0.f;
+                } else {
+                    const float4 t = ldf4(xp);
+                    xv[u][0] = ok ? t.x : 0.f, xv[u][1] = ok ? t.y : 0.f, xv[u][2] = ok ? t.z : 0.f, xv[u][3] = ok ? t.w : 0.f;
+                }
+                const T* gp = dy + (ok ? v : 0) * y_ld;
+                if constexpr (DYV) {
+                    typedef T tvec __attribute__((ext_vector_type(CO)));
+                    const tvec t = *reinterpret_cast<const tvec*>(gp);
+#pragma unroll
+                    for (int c = 0; c < CO; ++c) gv[u][c] = ok ? (float)t[c] : 0.f;
+                } else {
+#pragma unroll
+                    for (int c = 0; c < CO; ++c) gv[u][c] = (ok && c < Co) ? ldf(gp + c) : 0.f;
+                }
             }
 #pragma unroll
             for (int u = 0; u < U; ++u) {
 #pragma unroll
                 for (int c = 0; c < CO; ++c) {
-                    acc[0][c] += (double)(xv[u].x * gv[u][c]);
-                    acc[1][c] += (double)(xv[u].y * gv[u][c]);
-                    acc[2][c] += (double)(xv[u].z * gv[u][c]);
-                    acc[3][c] += (double)(xv[u].w * gv[u][c]);
+#pragma unroll
+                    for (int a = 0; a < VX; ++a) acc[a][c] += (double)(xv[u][a] * gv[u][c]);
                     if (q == 0) bsum[c] += (double)gv[u][c];
                 }
             }
         }
     }
-    constexpr int S = 5 * CO;
+    constexpr int S = (VX + 1) * CO;
 #pragma unroll
     for (int c = 0; c < CO; ++c) {
 #pragma unroll
-        for (int a = 0; a < 4; ++a) redd[tid * S + a * CO + c] = acc[a][c];
-        redd[tid * S + 4 * CO + c] = bsum[c];
+        for (int a = 0; a < VX; ++a) redd[tid * S + a * CO + c] = acc[a][c];
+        redd[tid * S + VX * CO + c] = bsum[c];
     }
     __syncthreads();
     // thread (q, a, c) sums over the VL voxel lanes
-    for (int o = tid; o < QC * 4 * CO; o += 256) {
-        const int c = o % CO, a = (o / CO) & 3, qq = o / (4 * CO);
+    for (int o = tid; o < QC * VX * CO; o += 256) {
+        const int c = o % CO, a = (o / CO) % VX, qq = o / (VX * CO);
         double s = 0.0;
         for (int l = 0; l < VL; ++l) s += redd[(l * QC + qq) * S + a * CO + c];
-        if (c < Co) part[((size_t)blockIdx.x * Co + c) * Ci + 4 * qq + a] = s;
+        if (c < Co) part[((size_t)blockIdx.x * Co + c) * Ci + VX * qq + a] = s;
     }
     if (bias_part != nullptr && tid < Co) {
         double s = 0.0;
-        for (int l = 0; l < VL; ++l) s += redd[(l * QC) * S + 4 * CO + tid];
+        for (int l = 0; l < VL; ++l) s += redd[(l * QC) * S + VX * CO + tid];
         bias_part[(size_t)blockIdx.x * Co + tid] = s;
     }
 }
@@ -197,19 +214,34 @@ int conv_pointwise_wgrad(const Mri3dConvGeom& g, const void* x, const void* dy, 
     double* bias_part = dbias ? part + (size_t)nb * g.co * g.ci : nullptr;
     const int64_t nvox = (int64_t)g.n * g.di * g.hi * g.wi;
     const int CO = g.co <= 2 ? 2 : (g.co <= 4 ? 4 : 8);
-    const size_t smem = (size_t)256 * 5 * CO * sizeof(double);
-#define PW_WGRAD(CO_)                                                                                                  \
+    // bf16: 8 channels per lane when the channel count and pitch allow 16-byte loads; one vector load of dy when it is dense
+    const bool v8 = g.dtype == MRI3D_BF16 && g.ci % 8 == 0 && g.x_ld % 8 == 0 && 256 % (g.ci / 8) == 0 && aligned16(x) && CO <= 4;
+    const bool dyv = g.co == CO && g.y_ld == CO && (reinterpret_cast<uintptr_t>(dy) & 15) == 0;
+    const size_t smem = (size_t)256 * ((v8 ? 8 : 4) + 1) * CO * sizeof(double);
+#define PW_WGRAD(CO_, VX_, DV_)                                                                                        \
     do {                                                                                                               \
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(pw_wgrad_kernel<T, CO_>),                              \
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);                              \
-        hipLaunchKernelGGL((pw_wgrad_kernel<T, CO_>), dim3(nb), dim3(256), smem, s, (const T*)x, (const T*)dy, part,   \
-                           bias_part, nvox, g.ci, g.co, g.x_ld, g.y_ld);                                               \
+        auto kern = pw_wgrad_kernel<T, CO_, VX_, DV_>;                                                                 \
+        static const hipError_t attr_ = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),                       \
+                                                            hipFuncAttributeMaxDynamicSharedMemorySize, 256 * 9 * 8 * 8); \
+        (void)attr_;                                                                                                   \
+        hipLaunchKernelGGL(kern, dim3(nb), dim3(256), smem, s, (const T*)x, (const T*)dy, part, bias_part, nvox, g.ci,  \
+                           g.co, g.x_ld, g.y_ld);                                                                      \
+    } while (0)
+#define PW_WGRAD_CO(CO_)                                                                                               \
+    do {                                                                                                               \
+        if constexpr (sizeof(T) == 2 && CO_ <= 4) {                                                                    \
+            if (v8 && dyv) { PW_WGRAD(CO_, 8, true); break; }                                                          \
+            if (v8) { PW_WGRAD(CO_, 8, false); break; }                                                                \
+        }                                                                                                              \
+        if (dyv) PW_WGRAD(CO_, 4, true);                                                                               \
+        else PW_WGRAD(CO_, 4, false);                                                                                  \
     } while (0)
     MRI3D_DISPATCH_DTYPE(g.dtype, T, {
-        if (CO == 2) PW_WGRAD(2);
-        else if (CO == 4) PW_WGRAD(4);
-        else PW_WGRAD(8);
+        if (CO == 2) PW_WGRAD_CO(2);
+        else if (CO == 4) PW_WGRAD_CO(4);
+        else PW_WGRAD_CO(8);
     });
+#undef PW_WGRAD_CO
 #undef PW_WGRAD
     hipLaunchKernelGGL(pw_wgrad_reduce_kernel, dim3(cdiv(g.co * g.ci + g.co, 8)), dim3(256), 0, s, part, bias_part, dw, dbias,
                        nb, g.ci, g.co);

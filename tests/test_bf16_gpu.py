@@ -46,6 +46,10 @@ CONV_CASES = [
     (1, 96, 32, (5, 8, 16), 3, 1, 1, 1),
     (2, 1, 8, (10, 12, 14), 3, 1, 1, 1),        # first layer
     (2, 16, 2, (10, 12, 14), 1, 1, 0, 1),       # classifier
+    (1, 32, 2, (9, 10, 11), 1, 1, 0, 1),        # pointwise heads: 8 channels per lane, vector dy loads; ragged voxel counts
+    (2, 64, 4, (5, 7, 9), 1, 1, 0, 1),
+    (1, 16, 5, (6, 7, 8), 1, 1, 0, 1),
+    (1, 24, 3, (6, 7, 8), 1, 1, 0, 1),
     (1, 8, 16, (11, 12, 13), 3, 2, 1, 1),       # strided (Modified3DUNet)
     (1, 4, 6, (9, 10, 11), (3, 1, 1), (2, 1, 1), (1, 0, 0), 1),
 ]
