@@ -749,3 +749,31 @@ def test_step_cache_replay_matches_eager_for_the_full_autoencoder_and_modified3d
             for (k, pa), pb in zip(a.named_parameters(), b.parameters()):
                 assert torch.equal(pa.grad, pb.grad), k
         assert ca.captures == 1 and ca.replays == 3
+
+
+def test_unet_split_decoder_conv_equals_the_shared_concat_buffer_scheme():
+    """The decoder's first convolution reads (skip, upsampled) as two dense tensors (ops.conv3d_cat, the default since round 2) or,
+    with `shared_concat_buffers`, one 3C-channel buffer that both producers wrote into (round 1): same kernels, same order of the
+    sums — logits, loss and every parameter gradient must be bit-identical."""
+    torch.manual_seed(4)
+    from mri_epilepsy_diagnosis_amd.unet import UNet
+    m = UNet(in_channels=1, out_classes=2, dimensions=3, num_encoding_blocks=3, out_channels_first_layer=8, normalization="batch",
+             upsampling_type="linear", padding=True, activation="PReLU").cuda().train()
+    x = torch.randn(2, 1, 48, 64, 80, device="cuda")
+    t = (torch.rand(2, 1, 48, 64, 80, device="cuda") < 0.2).float()
+    res = []
+    for shared in (False, True):
+        m.shared_concat_buffers = shared
+        m.zero_grad(set_to_none=True)
+        bufs = [b.detach().clone() for b in m.buffers()]
+        y = m(x)
+        loss = ops.softmax_dice_loss(y, t)
+        loss.backward()
+        res.append((y.detach().clone(), loss.detach().clone(), [p.grad.detach().clone() for p in m.parameters()]))
+        with torch.no_grad():
+            for b, s in zip(m.buffers(), bufs):
+                b.copy_(s)                                    # same running statistics for the second pass
+    (y0, l0, g0), (y1, l1, g1) = res
+    assert torch.equal(y0, y1) and torch.equal(l0, l1)
+    for a, b in zip(g0, g1):
+        assert torch.equal(a, b)
