@@ -621,12 +621,15 @@ upsample2x_fwd_kernel(Mri3dUpGeom g, const T* __restrict__ x, T* __restrict__ y,
         }
         __syncthreads();
         const int id = d0, ih = h0 + ihl, iw = w0 + iwl;
+        // the bf16 pair exchange needs both lanes of a quad pair active (channels in whole octets) and 16-byte aligned rows
+        const bool pair_ok = sizeof(T) == 2 && (g.c & 7) == 0 && (g.y_ld & 7) == 0 && ((reinterpret_cast<uintptr_t>(y) & 15) == 0);
         if (ih < g.hi && iw < g.wi && c0 + 4 * q < g.c) {
             const float4* base = cbuf + ((1 * FHH + (ihl + 1)) * FHW + (iwl + 1)) * 8 + q;   // the lane's own coarse voxel
 #pragma unroll
             for (int ed = 0; ed < 2; ++ed)
 #pragma unroll
-                for (int eh = 0; eh < 2; ++eh)
+                for (int eh = 0; eh < 2; ++eh) {
+                    float4 opair[2];
 #pragma unroll
                     for (int ew = 0; ew < 2; ++ew) {
                         // the second source voxel per axis lies at -1 for the even fine index and +1 for the odd one; the clamped
@@ -649,9 +652,32 @@ upsample2x_fwd_kernel(Mri3dUpGeom g, const T* __restrict__ x, T* __restrict__ y,
                                     o.z = fmaf(wgt, cv.z, o.z);
                                     o.w = fmaf(wgt, cv.w, o.w);
                                 }
-                        const int od = 2 * id + ed, oh = 2 * ih + eh, ow = 2 * iw + ew;
-                        stf4(y + ((((int64_t)n * g.dout + od) * g.ho + oh) * g.wo + ow) * g.y_ld + c0 + 4 * q, o);
+                        opair[ew] = o;
                     }
+                    const int od = 2 * id + ed, oh = 2 * ih + eh;
+                    T* yrow = y + ((((int64_t)n * g.dout + od) * g.ho + oh) * g.wo + 2 * iw) * g.y_ld + c0;
+                    if constexpr (sizeof(T) == 2) {
+                        // bf16: a quad is 8 bytes and the two fine voxels of a pair would each get half-line pieces from separate store
+                        // instructions (partial-line writes cost up to 3.6x, tools/slice_write_probe.py).  Adjacent quad lanes swap: the
+                        // even lane keeps the ew = 0 voxel and takes its neighbour's quad of it, the odd lane the ew = 1 voxel — one
+                        // 16-byte store per lane, and the eight lanes of a coarse voxel cover its two fine voxels contiguously.
+                        if (pair_ok) {
+                            const bool odd = q & 1;
+                            const float4 send = odd ? opair[0] : opair[1], keep = odd ? opair[1] : opair[0];
+                            float4 recv;
+                            recv.x = __shfl_xor(send.x, 1, 64), recv.y = __shfl_xor(send.y, 1, 64);
+                            recv.z = __shfl_xor(send.z, 1, 64), recv.w = __shfl_xor(send.w, 1, 64);
+                            const float4 lo = odd ? recv : keep, hi = odd ? keep : recv;   // channels 4(q & ~1) .. +7 of voxel ew = odd
+                            bf16x8_t o8;
+                            o8[0] = (bf16_t)lo.x, o8[1] = (bf16_t)lo.y, o8[2] = (bf16_t)lo.z, o8[3] = (bf16_t)lo.w;
+                            o8[4] = (bf16_t)hi.x, o8[5] = (bf16_t)hi.y, o8[6] = (bf16_t)hi.z, o8[7] = (bf16_t)hi.w;
+                            *reinterpret_cast<bf16x8_t*>(yrow + (odd ? g.y_ld : 0) + 4 * (q & ~1)) = o8;
+                            continue;
+                        }
+                    }
+                    stf4(yrow + 4 * q, opair[0]);
+                    stf4(yrow + g.y_ld + 4 * q, opair[1]);
+                }
         }
     }
 }
