@@ -184,6 +184,85 @@ maxpool_bwd_kernel(Mri3dPoolGeom g, const T* __restrict__ dy, const uint8_t* __r
     }
 }
 
+// ------------------------------------------------------------------ MaxPool3d(2) forward, line-contiguous lanes
+// kernel 2 / stride 2 / no padding on even extents (every pooling of the reference: cnn_model.py:115-148, unet.UNet).  In the slab
+// kernel above a lane owns an OUTPUT voxel: consecutive lanes read input voxels two apart, so every wave-load touches half of
+// each 128-byte line and the kw = 1 tap comes back for the other half.  Here a lane owns one INPUT column (2*ow + kw) x VEC
+// channels: consecutive lanes read consecutive bytes (whole lines per wave-load), take the maximum over their four (kd, kh)
+// taps, and the two kw lanes of an output voxel — CV lanes apart — are merged with one shuffle.  Same rule as the slab kernel
+// (first maximum in raster order wins, NaN propagates: the later NaN's index), same index bytes.
+template <typename T, int VEC>
+__global__ void __launch_bounds__(256)
+maxpool2_fwd_kernel(Mri3dPoolGeom g, const T* __restrict__ x, T* __restrict__ y, uint8_t* __restrict__ idx, int hch) {
+    const unsigned CV = g.c / VEC;            // lanes per voxel: a power of two <= 32 (host)
+    const int hchunks = (g.ho + hch - 1) / hch;
+    const int slabs = g.n * g.dout * hchunks;
+    const unsigned row = (unsigned)g.wi * g.x_ld, plane = (unsigned)g.hi * row;   // element strides of the input (one sample < 2^31)
+    for (int slab = blockIdx.x; slab < slabs; slab += gridDim.x) {
+        const int hc = slab % hchunks, nd = slab / hchunks;
+        const int n = nd / g.dout, od = nd - n * g.dout;
+        const int h0 = hc * hch, hn = min(hch, g.ho - h0);
+        const unsigned inner = (unsigned)hn * g.wi * CV;   // lanes walk (oh, input column iw, channel vector)
+        const T* xs = x + ((int64_t)n * g.di + 2 * od) * g.hi * g.wi * g.x_ld;
+        const int64_t obase = ((int64_t)nd * g.ho + h0) * g.wo;
+        for (unsigned e0 = 0; e0 < inner; e0 += blockDim.x) {   // whole block iterates together: the shuffle needs both kw lanes
+            const unsigned e = e0 + threadIdx.x;
+            const bool live = e < inner;
+            const unsigned ee = live ? e : 0;
+            const unsigned cv = ee % CV, col = ee / CV;
+            const unsigned iw = col % g.wi, ohl = col / g.wi;
+            const unsigned kw = iw & 1, ow = iw >> 1, oh = h0 + ohl;
+            const T* p0 = xs + (2 * oh) * row + iw * (unsigned)g.x_ld + cv * VEC;
+            V<VEC> v[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) v[t].load(p0 + (t >> 1) * plane + (t & 1) * row);
+            float best[VEC];
+            int bi[VEC];
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) { best[j] = v[0].v[j]; bi[j] = (int)kw; }
+#pragma unroll
+            for (int t = 1; t < 4; ++t)
+#pragma unroll
+                for (int j = 0; j < VEC; ++j)
+                    if (v[t].v[j] > best[j] || v[t].v[j] != v[t].v[j]) { best[j] = v[t].v[j]; bi[j] = 2 * t + (int)kw; }
+            // merge with the other kw lane (CV lanes away; wi is even and CV | 64, so both are in the same wave and both live)
+            V<VEC> o;
+            int oi[VEC];
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) {
+                const float pb = __shfl_xor(best[j], (int)CV, 64);
+                const int pi = __shfl_xor(bi[j], (int)CV, 64);
+                const bool mine_nan = best[j] != best[j], his_nan = pb != pb;
+                bool take_his;
+                if (mine_nan || his_nan) take_his = his_nan && (!mine_nan || pi > bi[j]);     // the LAST NaN in raster order
+                else take_his = pb > best[j] || (pb == best[j] && pi < bi[j]);                  // the FIRST maximum
+                o.v[j] = take_his ? pb : best[j];
+                oi[j] = take_his ? pi : bi[j];
+            }
+            if (live && kw == 0) {
+                const int64_t ov = obase + (int64_t)ohl * g.wo + ow;
+                o.store(y + ov * g.y_ld + cv * VEC);
+                uint8_t* ip = idx + ov * g.c + cv * VEC;
+                if constexpr (VEC == 8) {
+                    uint2 pk;
+                    pk.x = (uint32_t)oi[0] | ((uint32_t)oi[1] << 8) | ((uint32_t)oi[2] << 16) | ((uint32_t)oi[3] << 24);
+                    pk.y = (uint32_t)oi[4] | ((uint32_t)oi[5] << 8) | ((uint32_t)oi[6] << 16) | ((uint32_t)oi[7] << 24);
+                    *reinterpret_cast<uint2*>(ip) = pk;
+                } else {
+                    *reinterpret_cast<uint32_t*>(ip) = (uint32_t)oi[0] | ((uint32_t)oi[1] << 8) | ((uint32_t)oi[2] << 16) | ((uint32_t)oi[3] << 24);
+                }
+            }
+        }
+    }
+}
+
+static inline bool pool2_ok(const Mri3dPoolGeom& g, int vec) {
+    const int cv = g.c / vec;
+    return g.kd == 2 && g.kh == 2 && g.kw == 2 && g.sd == 2 && g.sh == 2 && g.sw == 2 && g.pd == 0 && g.ph == 0 && g.pw == 0 &&
+           g.di == 2 * g.dout && g.hi == 2 * g.ho && g.wi == 2 * g.wo && cv >= 1 && cv <= 32 && (cv & (cv - 1)) == 0 &&
+           (int64_t)g.di * g.hi * g.wi * g.x_ld < ((int64_t)1 << 31);
+}
+
 // ------------------------------------------------------------------ upsample coordinate helpers (torch semantics)
 struct Lin { int i0, i1; float l0, l1; };
 __device__ __forceinline__ Lin lin_src(int o, float r, int in_size, int align_corners) {
@@ -729,6 +808,16 @@ extern "C" int mri3d_maxpool3d_fwd(const Mri3dPoolGeom* g, const void* x, void* 
     const bool v8 = v4 && g->dtype == MRI3D_BF16 && g->c % 8 == 0 && g->x_ld % 8 == 0 && g->y_ld % 8 == 0 && aligned16(x, y) &&
                     (reinterpret_cast<uintptr_t>(idx) & 7) == 0;
     slab_plan(g->n * g->dout, g->ho, g->wo, g->c / (v8 ? 8 : (v4 ? 4 : 1)), hch, grid);
+    if (v4 && pool2_ok(*g, v8 ? 8 : 4)) {   // MaxPool3d(2) on even extents: lanes walk input columns (whole lines per wave-load)
+        slab_plan(g->n * g->dout, g->ho, g->wi, g->c / (v8 ? 8 : 4), hch, grid);
+        MRI3D_DISPATCH_DTYPE(g->dtype, T, {
+            if constexpr (sizeof(T) == 2) {
+                if (v8) hipLaunchKernelGGL((maxpool2_fwd_kernel<T, 8>), dim3(grid), dim3(256), 0, s, *g, (const T*)x, (T*)y, idx, hch);
+            }
+            if (!v8) hipLaunchKernelGGL((maxpool2_fwd_kernel<T, 4>), dim3(grid), dim3(256), 0, s, *g, (const T*)x, (T*)y, idx, hch);
+        });
+        return check_launch("maxpool3d_fwd");
+    }
     MRI3D_DISPATCH_DTYPE(g->dtype, T, {
         if constexpr (sizeof(T) == 2) {
             if (v8) hipLaunchKernelGGL((maxpool_fwd_kernel<T, 8>), dim3(grid), dim3(256), 0, s, *g, (const T*)x, (T*)y, idx, hch);
