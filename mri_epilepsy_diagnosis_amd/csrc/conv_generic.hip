@@ -445,6 +445,126 @@ conv_wgrad_small_kernel(Mri3dConvGeom g, const T* __restrict__ x, const T* __res
     }
 }
 
+// ------------------------------------------------------------------ weight gradient, few taps, channel QUADS
+// The encoder's separable convs (AE_model.py:9-26: (6,1,1)/(1,6,1)/(1,1,6) stride 2, 8 -> 8 ... 32 -> 32) have Ci, Co in multiples
+// of 4.  In the per-channel kernel above the 8 lanes of a voxel each fetch ONE 4-byte x value per tap and all re-read the same 32
+// bytes of dy: 8 load instructions per lane for 56 bytes (0.84 TB/s on 8 -> 8 (1,6,1) at 80x96x160).  Here a lane owns (voxel,
+// input-channel quad, output-channel quad): one 16-byte x load per tap, one 16-byte dy load, a taps x 4 x 4 register block.
+// Voxels are walked slab-wise — (n, od, h-chunk) per workgroup iteration, 32-bit arithmetic per element — instead of decoding a
+// 64-bit flat index per voxel.  Lanes are combined through LDS (double) once per workgroup: same partial layout and final
+// fixed-order sum as above (deterministic).
+// NTAPS = 4, 6 or 8 accumulator slots (the smallest that holds the filter: fewer registers, more resident waves to cover the latency)
+template <typename T, int NTAPS>
+__global__ void __launch_bounds__(256)
+conv_wgrad_quads_kernel(Mri3dConvGeom g, const T* __restrict__ x, const T* __restrict__ dy, float* __restrict__ part,
+                        float* __restrict__ bias_part, int QI, int QO, int hch, int CiP, int CoP) {
+    __shared__ float red[256 * 16];
+    const int taps = g.kd * g.kh * g.kw;
+    const int tid = threadIdx.x;
+    const int PV = QI * QO, VL = 256 / PV;           // lanes per voxel, voxel lanes per workgroup (PV divides 256: host)
+    const int pq = tid % PV, vl = tid / PV;
+    const int iq = pq % QI, oq = pq / QI;
+    float acc[NTAPS][4][4], bsum[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int t = 0; t < NTAPS; ++t)
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int b = 0; b < 4; ++b) acc[t][a][b] = 0.f;
+    int tkd[NTAPS], tkh[NTAPS], tkw[NTAPS];   // tap coordinates (uniform: scalar registers)
+#pragma unroll
+    for (int t = 0; t < NTAPS; ++t) {
+        const int tt = t < taps ? t : 0;
+        tkw[t] = tt % g.kw, tkh[t] = (tt / g.kw) % g.kh, tkd[t] = tt / (g.kw * g.kh);
+    }
+    const int hchunks = (g.ho + hch - 1) / hch;
+    const int slabs = g.n * g.dout * hchunks;
+    for (int slab = blockIdx.x; slab < slabs; slab += gridDim.x) {
+        const int hc = slab % hchunks, nd = slab / hchunks;
+        const int n = nd / g.dout, od = nd - n * g.dout;
+        const int h0 = hc * hch, hn = min(hch, g.ho - h0);
+        const unsigned inner = (unsigned)hn * g.wo;
+        const T* xn = x + (int64_t)n * g.di * g.hi * g.wi * g.x_ld + 4 * iq;
+        const T* yn = dy + (((int64_t)nd * g.ho + h0) * g.wo) * g.y_ld + 4 * oq;
+        // ALL tap loads of a voxel first, unconditional (clamped address, masked afterwards; taps past the filter re-read tap 0):
+        // a load inside `if (ok)` / `if (t < taps)` is followed by its own s_waitcnt and the taps become serial round trips to
+        // L2 (7 per voxel: 0.51 ms on the (1,6,1) 8 -> 8 layer at 80x96x160, waves waiting 73 % of their cycles; batched 0.31 ms).
+        auto fetch = [&](unsigned e, float4& gv, float4 (&xv)[NTAPS], unsigned& okm) {
+            const bool live = e < inner;
+            const unsigned ec = live ? e : inner - 1;
+            const int ow = ec % g.wo, oh = h0 + ec / g.wo;
+            gv = ldf4(yn + (int64_t)ec * g.y_ld);
+            okm = 0;
+#pragma unroll
+            for (int t = 0; t < NTAPS; ++t) {
+                const int id = od * g.sd - g.pd + tkd[t] * g.dd, ih = oh * g.sh - g.ph + tkh[t] * g.dh, iw = ow * g.sw - g.pw + tkw[t] * g.dw;
+                const bool ok = live && t < taps && (unsigned)id < (unsigned)g.di && (unsigned)ih < (unsigned)g.hi && (unsigned)iw < (unsigned)g.wi;
+                okm |= ok ? (1u << t) : 0u;
+                const int cd = min(max(id, 0), g.di - 1), chh = min(max(ih, 0), g.hi - 1), cw = min(max(iw, 0), g.wi - 1);
+                xv[t] = ldf4(xn + (((int64_t)cd * g.hi + chh) * g.wi + cw) * g.x_ld);
+            }
+            if (!live) gv = make_float4(0.f, 0.f, 0.f, 0.f);
+        };
+        auto consume = [&](const float4& gv, const float4 (&xv)[NTAPS], unsigned okm) {
+            const float gq[4] = {gv.x, gv.y, gv.z, gv.w};
+            if (iq == 0) {
+#pragma unroll
+                for (int b = 0; b < 4; ++b) bsum[b] += gq[b];
+            }
+#pragma unroll
+            for (int t = 0; t < NTAPS; ++t) {
+                const bool ok = (okm >> t) & 1u;
+                const float xq[4] = {ok ? xv[t].x : 0.f, ok ? xv[t].y : 0.f, ok ? xv[t].z : 0.f, ok ? xv[t].w : 0.f};
+#pragma unroll
+                for (int a = 0; a < 4; ++a)
+#pragma unroll
+                    for (int b = 0; b < 4; ++b) acc[t][a][b] = fmaf(xq[a], gq[b], acc[t][a][b]);
+            }
+        };
+        // (a second register set for the next voxel's loads was measured: with 128 accumulators it pushes the kernel to 256 VGPRs
+        //  and 80 spilled SGPRs and is slower, 0.50 vs 0.31 ms; fewer accumulator slots and more waves hide the latency instead)
+        for (unsigned e = vl; e < inner; e += VL) {
+            float4 gv, xv[NTAPS];
+            unsigned okm;
+            fetch(e, gv, xv, okm);
+            consume(gv, xv, okm);
+        }
+    }
+    // combine the VL voxel lanes of every (tap, ci, co) through LDS, in double, in a fixed order
+    for (int t = 0; t < taps; ++t) {
+        __syncthreads();
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                float val = 0.f;
+#pragma unroll
+                for (int tt = 0; tt < NTAPS; ++tt)
+                    if (tt == t) val = acc[tt][a][b];
+                red[tid * 16 + a * 4 + b] = val;
+            }
+        __syncthreads();
+        for (int o = tid; o < PV * 16; o += 256) {
+            const int ab = o % 16, q = o / 16;
+            double sdbl = 0.0;
+            for (int l = 0; l < VL; ++l) sdbl += (double)red[(l * PV + q) * 16 + ab];
+            const int ci = (q % QI) * 4 + ab / 4, co = (q / QI) * 4 + ab % 4;
+            if (ci < g.ci && co < g.co) part[(((size_t)blockIdx.x * taps + t) * CiP + ci) * CoP + co] = (float)sdbl;
+        }
+    }
+    if (bias_part != nullptr) {
+        __syncthreads();
+#pragma unroll
+        for (int b = 0; b < 4; ++b) red[tid * 4 + b] = (iq == 0) ? bsum[b] : 0.f;
+        __syncthreads();
+        if (tid < g.co) {
+            double sdbl = 0.0;
+            for (int l = 0; l < VL; ++l) sdbl += (double)red[((l * PV) + (tid / 4) * QI) * 4 + (tid % 4)];
+            bias_part[(size_t)blockIdx.x * g.co + tid] = (float)sdbl;
+        }
+    }
+}
+
 // ------------------------------------------------------------------ weight gradient, few taps, ONE output channel
 // The decoder's last separable convs end in a single channel (8 -> 1 and 1 -> 1 with (3,1,1)/(1,3,1)/(1,1,3) kernels at full
 // resolution, AE_model.py:110-160).  In the kernel above a lane owns one input channel and reads it 4 bytes at a time while 7 of
@@ -887,6 +1007,31 @@ static bool wgrad_small_ok(const Mri3dConvGeom& g) {
     return taps <= kSmTaps && g.ci <= 64 && g.co <= 64 && (int64_t)g.dout * g.ho * g.wo < 0x7fffffffLL;
 }
 
+// the channel-quad variant: Ci, Co multiples of 4 with QI * QO lanes per voxel dividing 256 (<= 64), 16-byte aligned rows
+static bool wgrad_quads_ok(const Mri3dConvGeom& g) {
+    const int taps = g.kd * g.kh * g.kw;
+    const int pv = (g.ci / 4) * (g.co / 4);
+    return taps <= kSmTaps && g.ci % 4 == 0 && g.co % 4 == 0 && g.ci >= 4 && g.co >= 4 && pv <= 64 && 256 % pv == 0 &&
+           g.x_ld % 4 == 0 && g.y_ld % 4 == 0 && (int64_t)g.ho * g.wo < 0x7fffffffLL &&
+           (int64_t)g.n * g.dout * g.ho < 0x7fffffffLL;
+}
+struct WgradQuadsPlan { int QI, QO, hch, gx, CiP, CoP; size_t part_floats, bias_floats; };
+static WgradQuadsPlan wgrad_quads_plan(const Mri3dConvGeom& g) {
+    WgradQuadsPlan p;
+    p.QI = g.ci / 4, p.QO = g.co / 4, p.CiP = g.ci, p.CoP = g.co;
+    const int VL = 256 / (p.QI * p.QO);
+    // ~16 voxels per lane and slab
+    p.hch = (int)std::max<int64_t>(1, std::min<int64_t>(g.ho, (int64_t)16 * VL / std::max(g.wo, 1)));
+    const int64_t slabs = (int64_t)g.n * g.dout * cdiv(g.ho, p.hch);
+    // one resident round: 4 / 3 / 2 workgroups per CU with 4 / 6 / 8 accumulator slots (112 / 161 / 209 VGPRs)
+    const int taps = g.kd * g.kh * g.kw;
+    const int resident = 256 * (taps <= 4 ? 4 : (taps <= 6 ? 3 : 2));
+    p.gx = (int)std::max<int64_t>(1, std::min<int64_t>(slabs, resident));
+    p.part_floats = (size_t)p.gx * g.kd * g.kh * g.kw * p.CiP * p.CoP;
+    p.bias_floats = (size_t)p.gx * g.co;
+    return p;
+}
+
 struct WgradSmallPlan { int CiL, gz, gy, gx, CiP, CoP; size_t part_floats, bias_floats; };
 static WgradSmallPlan wgrad_small_plan(const Mri3dConvGeom& g) {
     WgradSmallPlan p;
@@ -955,6 +1100,10 @@ size_t conv_generic_workspace_bytes(const Mri3dConvGeom& g, int pass) {
     if (wgrad_co1_ok(g)) a = std::max(a, (size_t)kCo1Blocks * (kSmTaps * 16 + 1) * sizeof(float));
     if (wgrad_small_ok(g)) {
         WgradSmallPlan q = wgrad_small_plan(g);
+        a = std::max(a, (q.part_floats + q.bias_floats) * sizeof(float));
+    }
+    if (wgrad_quads_ok(g)) {
+        WgradQuadsPlan q = wgrad_quads_plan(g);
         a = std::max(a, (q.part_floats + q.bias_floats) * sizeof(float));
     }
     return a;
@@ -1195,6 +1344,27 @@ int conv_generic_wgrad(const Mri3dConvGeom& g, const void* x, const void* dy, fl
         hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(cdiv(taps * g.ci + 1, 8)), dim3(256), 0, s, part, bias_part, dw, dbias, nb, taps,
                            g.ci, 1, g.ci, 1);
         return check_launch("conv3d_wgrad(co1)");
+    }
+    if (wgrad_quads_ok(g) && aligned_vec4(g.dtype, x, dy)) {
+        WgradQuadsPlan q = wgrad_quads_plan(g);
+        const size_t need = (q.part_floats + q.bias_floats) * sizeof(float);
+        MRI3D_REQUIRE(ws != nullptr && ws_bytes >= need, MRI3D_EWORKSPACE, "conv3d_wgrad: workspace %zu < %zu", ws_bytes, need);
+        float* part = static_cast<float*>(ws);
+        float* bias_part = dbias ? part + q.part_floats : nullptr;
+        const int taps = g.kd * g.kh * g.kw;
+#define MRI3D_WGQ(NTv)                                                                                                 \
+    hipLaunchKernelGGL((conv_wgrad_quads_kernel<T, NTv>), dim3(q.gx), dim3(256), 0, s, g, (const T*)x, (const T*)dy, part,  \
+                       bias_part, q.QI, q.QO, q.hch, q.CiP, q.CoP)
+        MRI3D_DISPATCH_DTYPE(g.dtype, T, {
+            if (taps <= 4) MRI3D_WGQ(4);
+            else if (taps <= 6) MRI3D_WGQ(6);
+            else MRI3D_WGQ(8);
+        });
+#undef MRI3D_WGQ
+        const int total = g.co * g.ci * taps;
+        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(cdiv(total + g.co, 8)), dim3(256), 0, s, part, bias_part, dw, dbias, q.gx, taps,
+                           g.ci, g.co, q.CiP, q.CoP);
+        return check_launch("conv3d_wgrad(quads)");
     }
     if (wgrad_small_ok(g)) {
         WgradSmallPlan q = wgrad_small_plan(g);

@@ -1,0 +1,39 @@
+"""One Conv3d geometry of the separable-conv autoencoder (AE_model.py:9-26) through the C ABI, for timing and rocprofv3 --pmc runs:
+   python tools/sep_conv_bench.py CI CO KD KH KW SD SH SW PD PH PW D H W [N] [reps] [passes=fwd,dgrad,wgrad] [f32|bf16]"""
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from mri_epilepsy_diagnosis_amd import ops  # noqa: E402
+
+a = sys.argv[1:]
+ci, co, kd, kh, kw, sd, sh, sw, pd, ph, pw, d, h, w = (int(v) for v in a[:14])
+n = int(a[14]) if len(a) > 14 else 4
+reps = int(a[15]) if len(a) > 15 else 10
+passes = a[16].split(",") if len(a) > 16 else ["fwd", "dgrad", "wgrad"]
+dt = torch.bfloat16 if (len(a) > 17 and a[17] == "bf16") else torch.float32
+dev = torch.device("cuda")
+g0 = torch.Generator(device=dev).manual_seed(0)
+x = torch.randn(n, ci, d, h, w, device=dev, generator=g0).to(dt).contiguous(memory_format=torch.channels_last_3d)
+wt = torch.randn(co, ci, kd, kh, kw, device=dev, generator=g0) * 0.1
+b = torch.randn(co, device=dev, generator=g0)
+geom = ops._conv_geom(x.shape, wt.shape, (sd, sh, sw), (pd, ph, pw), (1, 1, 1), dtype=ops._dt(x))
+dy = torch.randn(n, co, geom.dout, geom.ho, geom.wo, device=dev, generator=g0).to(dt).contiguous(memory_format=torch.channels_last_3d)
+es = x.element_size()
+byt = {"fwd": (x.numel() + dy.numel()) * es, "dgrad": (x.numel() + dy.numel()) * es, "wgrad": (x.numel() + dy.numel()) * es}
+fns = {"fwd": lambda: ops._conv_fwd(geom, x, wt, b), "dgrad": lambda: ops._conv_dgrad(geom, dy, wt, None, x),
+       "wgrad": lambda: ops._conv_wgrad(geom, x, dy, wt, True)}
+for p in passes:
+    fn = fns[p]
+    fn(); fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / reps
+    print("%-5s %d->%d k(%d,%d,%d) s(%d,%d,%d) @%dx%dx%d n%d %s: %.3f ms  %.0f GB/s (in+out once)" % (p, ci, co, kd, kh, kw, sd, sh, sw, d, h, w, n, str(dt)[6:], ms, byt[p] / ms / 1e6), flush=True)
