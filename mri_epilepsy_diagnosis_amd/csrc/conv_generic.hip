@@ -1132,6 +1132,130 @@ conv_c1c1_wgrad_kernel(Mri3dConvGeom g, const T* __restrict__ x, const T* __rest
 
 constexpr int kC1C1Blocks = 1024;
 
+// ------------------------------------------------------------------ 1 -> 1 channel, few taps (the autoencoder's last separable convs)
+// Conv3d(1, 1, (1,3,1) / (1,1,3) ...) at full resolution (AE_model.py:110-160): a one-channel tensor is a dense float array, so a lane
+// takes FOUR consecutive voxels of a row as one 16-byte access and a tap is the same access shifted by a wave-uniform element
+// offset (4-byte aligned: global dwordx4 loads do not need more).  Forward and stride-1 data gradient are the same stencil (the
+// gradient walks the taps with the opposite sign); the weight gradient is taps + 1 dot products reduced per wave (DPP), per
+// workgroup (LDS, double) and across workgroups (wgrad_reduce_kernel: fixed order).  fp32, stride 1, <= 8 taps, W % 4 == 0.
+// The gather kernels spent 0.11 - 0.18 ms per pass on 4 x 160x192x160 (1 TB/s) on 64-bit index arithmetic per voxel.
+constexpr int kC1TBlocks = 1024;
+
+// sign = +1: y[o] = b + sum_t w[t] x[o - p + k_t d]   (forward);   sign = -1: dx[i] = sum_t w[t] dy[i + p - k_t d]   (data gradient)
+__global__ void __launch_bounds__(256)
+conv_c1_taps_kernel(Mri3dConvGeom g, const float* __restrict__ src, const float* __restrict__ w, const float* __restrict__ bias,
+                    float* __restrict__ dst, int sign, int sD, int sH, int sW, int oD, int oH, int oW) {
+    const int taps = g.kd * g.kh * g.kw;
+    const int W4 = oW >> 2;
+    const int64_t rows = (int64_t)g.n * oD * oH;
+    const float b0 = bias != nullptr ? bias[0] : 0.f;
+    for (int64_t item = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; item < rows * W4; item += (int64_t)gridDim.x * blockDim.x) {
+        const int q = (int)(item % W4);
+        int64_t r = item / W4;
+        const int oh = (int)(r % oH);
+        r /= oH;
+        const int od = (int)(r % oD), n = (int)(r / oD);
+        const int ow = 4 * q;
+        const float* sn = src + (int64_t)n * sD * sH * sW;
+        float4 xv[kSmTaps];
+        unsigned vm[kSmTaps];
+#pragma unroll
+        for (int t = 0; t < kSmTaps; ++t) {
+            const int tt = t < taps ? t : 0;
+            const int kw = tt % g.kw, kh = (tt / g.kw) % g.kh, kd = tt / (g.kw * g.kh);
+            const int sd_ = od + sign * (kd * g.dd - g.pd), sh_ = oh + sign * (kh * g.dh - g.ph), sw_ = ow + sign * (kw * g.dw - g.pw);
+            const bool rowok = t < taps && (unsigned)sd_ < (unsigned)sD && (unsigned)sh_ < (unsigned)sH;
+            unsigned m = 0;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) m |= (rowok && (unsigned)(sw_ + j) < (unsigned)sW) ? (1u << j) : 0u;
+            vm[t] = m;
+            const float* p = sn + ((int64_t)(rowok ? sd_ : 0) * sH + (rowok ? sh_ : 0)) * sW;
+            if (m == 15u) {
+                xv[t] = *reinterpret_cast<const float4*>(p + sw_);          // 4-byte aligned 16-byte load
+            } else {   // row ends / outside: element-wise (a handful of lanes per row)
+                xv[t].x = (m & 1u) ? p[sw_] : 0.f;
+                xv[t].y = (m & 2u) ? p[sw_ + 1] : 0.f;
+                xv[t].z = (m & 4u) ? p[sw_ + 2] : 0.f;
+                xv[t].w = (m & 8u) ? p[sw_ + 3] : 0.f;
+            }
+        }
+        float4 acc = make_float4(b0, b0, b0, b0);
+#pragma unroll
+        for (int t = 0; t < kSmTaps; ++t) {
+            if (t < taps) {
+                const float wt = w[t];
+                acc.x = fmaf(xv[t].x, wt, acc.x);
+                acc.y = fmaf(xv[t].y, wt, acc.y);
+                acc.z = fmaf(xv[t].z, wt, acc.z);
+                acc.w = fmaf(xv[t].w, wt, acc.w);
+            }
+        }
+        *reinterpret_cast<float4*>(dst + (((int64_t)n * oD + od) * oH + oh) * oW + ow) = acc;
+    }
+}
+
+// part[b][t] = sum over the workgroup's voxels of x[o - p + k_t d] * dy[o];  bias_part[b] = sum dy
+__global__ void __launch_bounds__(256)
+conv_c1_taps_wgrad_kernel(Mri3dConvGeom g, const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ part,
+                          float* __restrict__ bias_part) {
+    __shared__ double red[4][kSmTaps + 1];
+    const int taps = g.kd * g.kh * g.kw;
+    const int W4 = g.wo >> 2;
+    const int64_t rows = (int64_t)g.n * g.dout * g.ho;
+    float acc[kSmTaps + 1];
+#pragma unroll
+    for (int t = 0; t <= kSmTaps; ++t) acc[t] = 0.f;
+    for (int64_t item = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; item < rows * W4; item += (int64_t)gridDim.x * blockDim.x) {
+        const int q = (int)(item % W4);
+        int64_t r = item / W4;
+        const int oh = (int)(r % g.ho);
+        r /= g.ho;
+        const int od = (int)(r % g.dout), n = (int)(r / g.dout);
+        const int ow = 4 * q;
+        const float4 gv = *reinterpret_cast<const float4*>(dy + (((int64_t)n * g.dout + od) * g.ho + oh) * g.wo + ow);
+        acc[kSmTaps] += (gv.x + gv.y) + (gv.z + gv.w);
+        const float* xn = x + (int64_t)n * g.di * g.hi * g.wi;
+#pragma unroll
+        for (int t = 0; t < kSmTaps; ++t) {
+            const int tt = t < taps ? t : 0;
+            const int kw = tt % g.kw, kh = (tt / g.kw) % g.kh, kd = tt / (g.kw * g.kh);
+            const int id = od - g.pd + kd * g.dd, ih = oh - g.ph + kh * g.dh, iw = ow - g.pw + kw * g.dw;
+            const bool rowok = t < taps && (unsigned)id < (unsigned)g.di && (unsigned)ih < (unsigned)g.hi;
+            const float* p = xn + ((int64_t)(rowok ? id : 0) * g.hi + (rowok ? ih : 0)) * g.wi;
+            float4 xv;
+            if (rowok && iw >= 0 && iw + 3 < g.wi) {
+                xv = *reinterpret_cast<const float4*>(p + iw);
+            } else {
+                xv.x = (rowok && (unsigned)iw < (unsigned)g.wi) ? p[iw] : 0.f;
+                xv.y = (rowok && (unsigned)(iw + 1) < (unsigned)g.wi) ? p[iw + 1] : 0.f;
+                xv.z = (rowok && (unsigned)(iw + 2) < (unsigned)g.wi) ? p[iw + 2] : 0.f;
+                xv.w = (rowok && (unsigned)(iw + 3) < (unsigned)g.wi) ? p[iw + 3] : 0.f;
+            }
+            acc[t] = fmaf(xv.x, gv.x, fmaf(xv.y, gv.y, fmaf(xv.z, gv.z, fmaf(xv.w, gv.w, acc[t]))));
+        }
+    }
+    // wave sums (fixed butterfly), then the four waves in double through LDS
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+    for (int t = 0; t <= kSmTaps; ++t) {
+        float v = acc[t];
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
+        if (lane == 0) red[wv][t] = (double)v;
+    }
+    __syncthreads();
+    if (threadIdx.x <= kSmTaps) {
+        const double sdbl = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+        if ((int)threadIdx.x < taps) part[(size_t)blockIdx.x * taps + threadIdx.x] = (float)sdbl;
+        if (threadIdx.x == kSmTaps && bias_part != nullptr) bias_part[blockIdx.x] = (float)sdbl;
+    }
+}
+
+static bool c1_taps_ok(const Mri3dConvGeom& g) {
+    return g.dtype == MRI3D_F32 && g.ci == 1 && g.co == 1 && g.kd * g.kh * g.kw <= kSmTaps && g.sd == 1 && g.sh == 1 && g.sw == 1 &&
+           g.x_ld == 1 && g.y_ld == 1 && g.wo % 4 == 0 && g.wi % 4 == 0 && !(g.kd == 3 && g.kh == 3 && g.kw == 3);
+}
+
 static bool c1c1_ok(const Mri3dConvGeom& g) {
     static const int off = tuning_knob("MRI3D_C1C1_OFF", 0);   // tuning aid (A/B)
     return !off && g.ci == 1 && g.co == 1 && g.kd == 3 && g.kh == 3 && g.kw == 3 && g.sd == 1 && g.sh == 1 && g.sw == 1 &&
@@ -1252,6 +1376,7 @@ size_t conv_generic_workspace_bytes(const Mri3dConvGeom& g, int pass) {
     size_t a = (p.part_floats + p.bias_floats) * sizeof(float);
     if (cin1_ok(g)) a = std::max(a, (size_t)kCin1Shares * (27 + 1) * g.co * sizeof(float));
     if (c1c1_ok(g)) a = std::max(a, (size_t)kC1C1Blocks * 28 * sizeof(float));
+    if (c1_taps_ok(g)) a = std::max(a, (size_t)kC1TBlocks * (kSmTaps + 1) * sizeof(float));
     if (wgrad_co1_ok(g)) a = std::max(a, (size_t)kCo1Blocks * (kSmTaps * 16 + 1) * sizeof(float));
     if (wgrad_small_ok(g)) {
         WgradSmallPlan q = wgrad_small_plan(g);
@@ -1297,6 +1422,13 @@ int conv_generic_fwd(const Mri3dConvGeom& g, const void* x, const float* w, cons
     if (c1c1_ok(g)) {
         MRI3D_DISPATCH_DTYPE(g.dtype, T, { launch_c1c1_stencil<T>(g, (const T*)x, g.x_ld, w, bias, 0, (T*)y, g.y_ld, s); });
         return check_launch("conv3d_fwd(1->1 stencil)");
+    }
+    if (c1_taps_ok(g) && aligned16(y)) {
+        const int64_t items = (int64_t)g.n * g.dout * g.ho * (g.wo / 4);
+        const int grid = (int)std::max<int64_t>(1, std::min<int64_t>(cdiv64(items, 256), 8192));
+        hipLaunchKernelGGL(conv_c1_taps_kernel, dim3(grid), dim3(256), 0, s, g, (const float*)x, w, bias, (float*)y, 1, g.di, g.hi,
+                           g.wi, g.dout, g.ho, g.wo);
+        return check_launch("conv3d_fwd(1->1 taps)");
     }
     if (cin1_ok(g) && aligned_vec4(g.dtype, y)) {
         const size_t need1 = (size_t)27 * g.co * sizeof(float);
@@ -1450,6 +1582,13 @@ int conv_generic_dgrad(const Mri3dConvGeom& g, const void* dy, const float* w, c
         MRI3D_DISPATCH_DTYPE(g.dtype, T, { launch_c1c1_stencil<T>(g, (const T*)dy, g.y_ld, w, bias, 1, (T*)dx, g.x_ld, s); });
         return check_launch("conv3d_dgrad(1->1 stencil)");
     }
+    if (c1_taps_ok(g) && aligned16(dx)) {
+        const int64_t items = (int64_t)g.n * g.di * g.hi * (g.wi / 4);
+        const int grid = (int)std::max<int64_t>(1, std::min<int64_t>(cdiv64(items, 256), 8192));
+        hipLaunchKernelGGL(conv_c1_taps_kernel, dim3(grid), dim3(256), 0, s, g, (const float*)dy, w, bias, (float*)dx, -1, g.dout,
+                           g.ho, g.wo, g.di, g.hi, g.wi);
+        return check_launch("conv3d_dgrad(1->1 taps)");
+    }
     const int taps = g.kd * g.kh * g.kw;
     const int TL = pick_tile(g.ci);
     const int CiP = cdiv(g.ci, TL) * TL;
@@ -1485,6 +1624,18 @@ int conv_generic_wgrad(const Mri3dConvGeom& g, const void* x, const void* dy, fl
         });
         hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(cdiv(27 + 1, 8)), dim3(256), 0, s, part, bias_part, dw, dbias, nb, 27, 1, 1, 1, 1);
         return check_launch("conv3d_wgrad(1->1 stencil)");
+    }
+    if (c1_taps_ok(g) && aligned16(dy)) {
+        const int taps = g.kd * g.kh * g.kw;
+        const int64_t items = (int64_t)g.n * g.dout * g.ho * (g.wo / 4);
+        const int nb = (int)std::max<int64_t>(1, std::min<int64_t>(cdiv64(items, 256 * 4), kC1TBlocks));
+        const size_t need = (size_t)kC1TBlocks * (kSmTaps + 1) * sizeof(float);
+        MRI3D_REQUIRE(ws != nullptr && ws_bytes >= need, MRI3D_EWORKSPACE, "conv3d_wgrad: workspace %zu < %zu", ws_bytes, need);
+        float* part = static_cast<float*>(ws);
+        float* bias_part = dbias ? part + (size_t)kC1TBlocks * kSmTaps : nullptr;
+        hipLaunchKernelGGL(conv_c1_taps_wgrad_kernel, dim3(nb), dim3(256), 0, s, g, (const float*)x, (const float*)dy, part, bias_part);
+        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(cdiv(taps + 1, 8)), dim3(256), 0, s, part, bias_part, dw, dbias, nb, taps, 1, 1, 1, 1);
+        return check_launch("conv3d_wgrad(1->1 taps)");
     }
     if (cin1_ok(g) && aligned_vec4(g.dtype, dy)) {
         const size_t need = (size_t)kCin1Shares * (27 + 1) * g.co * sizeof(float);

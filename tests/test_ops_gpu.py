@@ -49,6 +49,15 @@ CONV_CASES = [
     ("dilated_p3", 1, 4, 4, (11, 12, 13), 3, 1, 3, 3, True),
     ("reduce_k4s4", 1, 1, 1, (16, 12, 8), 4, 4, 0, 1, True),
     ("vox_1_1", 2, 1, 1, (9, 10, 11), 3, 1, 1, 1, True),
+    # 1 -> 1 separable convs of the autoencoder's last block (AE_model.py:110-160): the 16-byte stencil kernels (W % 4 == 0) ...
+    ("c1_sepy", 2, 1, 1, (9, 10, 12), (1, 3, 1), 1, (0, 1, 0), 1, True),
+    ("c1_sepz", 2, 1, 1, (5, 7, 16), (1, 1, 3), 1, (0, 0, 1), 1, True),
+    ("c1_sepx_nobias", 1, 1, 1, (6, 5, 8), (3, 1, 1), 1, (1, 0, 0), 1, False),
+    ("c1_sepz_k6_p2", 1, 1, 1, (4, 6, 20), (1, 1, 6), 1, (0, 0, 2), 1, True),      # output narrower than the input (W 20 -> 19: gather path)
+    ("c1_sepz_k5_p2_dil2", 1, 1, 1, (4, 6, 24), (1, 1, 5), 1, (0, 0, 4), 2, True),  # dilation 2, same width: shifted 16-byte loads
+    ("c1_sepy_k2", 2, 1, 1, (4, 9, 8), (1, 2, 1), 1, (0, 1, 0), 1, True),           # even filter: H 9 -> 10
+    # ... and a width that is not a multiple of 4 (gather kernels)
+    ("c1_sepz_ragged", 1, 1, 1, (5, 6, 10), (1, 1, 3), 1, (0, 0, 1), 1, True),
     ("odd_channels", 1, 3, 5, (6, 7, 8), 3, 1, 1, 1, True),
     ("wide_128", 1, 128, 128, (4, 4, 4), 3, 1, 1, 1, False),
 ]
