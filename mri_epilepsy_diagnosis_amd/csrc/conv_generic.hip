@@ -114,7 +114,8 @@ conv_fwd_generic_kernel(Mri3dConvGeom g, const T* __restrict__ x, const float* _
 // sits inside nested run-time loops behind `valid ? load : 0`, so it gets its own wait (12 serial round trips per voxel of the 8 -> 8
 // layer) and each voxel pays three 64-bit divisions.  Here voxels are walked slab-wise with 32-bit arithmetic and, per input-channel
 // quad, the loads of ALL taps are issued together (clamped address, masked afterwards) before their FMAs.
-template <typename T, int COT, int NTAPS>
+// CV = input channels per load: 4 (Ci % 4 == 0, 16-byte loads) or 1 (any Ci; the autoencoder's first conv has Ci = 1)
+template <typename T, int COT, int NTAPS, int CV>
 __global__ void __launch_bounds__(256)
 conv_fwd_taps_kernel(Mri3dConvGeom g, const T* __restrict__ x, const float* __restrict__ wp, const float* __restrict__ bias,
                      T* __restrict__ y, int CoP, int hch) {
@@ -155,22 +156,27 @@ conv_fwd_taps_kernel(Mri3dConvGeom g, const T* __restrict__ x, const float* __re
             float acc[COT];
 #pragma unroll
             for (int j = 0; j < COT; ++j) acc[j] = (bias != nullptr && cot + j < g.co) ? bias[cot + j] : 0.f;
-            for (int ci = 0; ci < g.ci; ci += 4) {
-                float4 xv[NTAPS];
+            for (int ci = 0; ci < g.ci; ci += CV) {
+                float xv[NTAPS][CV];
 #pragma unroll
-                for (int t = 0; t < NTAPS; ++t) xv[t] = ldf4(xn + off[t] + ci);
+                for (int t = 0; t < NTAPS; ++t) {
+                    if constexpr (CV == 4) {
+                        const float4 q = ldf4(xn + off[t] + ci);
+                        xv[t][0] = q.x, xv[t][1] = q.y, xv[t][2] = q.z, xv[t][3] = q.w;
+                    } else {
+                        xv[t][0] = ldf(xn + off[t] + ci);
+                    }
+                }
 #pragma unroll
                 for (int t = 0; t < NTAPS; ++t) {
                     if (t < taps) {   // uniform
                         const bool ok = (okm >> t) & 1u;
-                        const float x0 = ok ? xv[t].x : 0.f, x1 = ok ? xv[t].y : 0.f, x2 = ok ? xv[t].z : 0.f, x3 = ok ? xv[t].w : 0.f;
                         const float* w0 = wp + ((size_t)t * g.ci + ci) * CoP + cot;
 #pragma unroll
-                        for (int j = 0; j < COT; ++j) {
-                            acc[j] = fmaf(x0, w0[j], acc[j]);
-                            acc[j] = fmaf(x1, w0[CoP + j], acc[j]);
-                            acc[j] = fmaf(x2, w0[2 * CoP + j], acc[j]);
-                            acc[j] = fmaf(x3, w0[3 * CoP + j], acc[j]);
+                        for (int c = 0; c < CV; ++c) {
+                            const float xc = ok ? xv[t][c] : 0.f;
+#pragma unroll
+                            for (int j = 0; j < COT; ++j) acc[j] = fmaf(xc, w0[c * CoP + j], acc[j]);
                         }
                     }
                 }
@@ -256,7 +262,8 @@ conv_dgrad_generic_kernel(Mri3dConvGeom g, const T* __restrict__ dy, const float
 // The gather above with slab-wise 32-bit voxel arithmetic and, per output-channel quad, the dy loads of ALL taps issued together
 // (clamped address, masked afterwards: taps that do not reach this input voxel — wrong stride residue, outside the volume — cost a
 // cached load instead of a branch with its own wait).  <= 8 taps, Co in multiples of 4.
-template <typename T, int CIT, int NTAPS>
+// CV = output channels per dy load: 4 (Co % 4 == 0) or 1 (Co = 1: the 8 -> 1 convs in front of the autoencoder's last block)
+template <typename T, int CIT, int NTAPS, int CV>
 __global__ void __launch_bounds__(256)
 conv_dgrad_taps_kernel(Mri3dConvGeom g, const T* __restrict__ dy, const float* __restrict__ wp, const float* __restrict__ bias,
                        T* __restrict__ dx, int CiP, int hch) {
@@ -294,22 +301,27 @@ conv_dgrad_taps_kernel(Mri3dConvGeom g, const T* __restrict__ dy, const float* _
             float acc[CIT];
 #pragma unroll
             for (int j = 0; j < CIT; ++j) acc[j] = (bias != nullptr && cit + j < g.ci) ? bias[cit + j] : 0.f;
-            for (int co = 0; co < g.co; co += 4) {
-                float4 gv[NTAPS];
+            for (int co = 0; co < g.co; co += CV) {
+                float gv[NTAPS][CV];
 #pragma unroll
-                for (int t = 0; t < NTAPS; ++t) gv[t] = ldf4(yn + off[t] + co);
+                for (int t = 0; t < NTAPS; ++t) {
+                    if constexpr (CV == 4) {
+                        const float4 q = ldf4(yn + off[t] + co);
+                        gv[t][0] = q.x, gv[t][1] = q.y, gv[t][2] = q.z, gv[t][3] = q.w;
+                    } else {
+                        gv[t][0] = ldf(yn + off[t] + co);
+                    }
+                }
 #pragma unroll
                 for (int t = 0; t < NTAPS; ++t) {
                     if (t < taps) {   // uniform
                         const bool ok = (okm >> t) & 1u;
-                        const float g0 = ok ? gv[t].x : 0.f, g1 = ok ? gv[t].y : 0.f, g2 = ok ? gv[t].z : 0.f, g3 = ok ? gv[t].w : 0.f;
                         const float* w0 = wp + ((size_t)t * g.co + co) * CiP + cit;
 #pragma unroll
-                        for (int j = 0; j < CIT; ++j) {
-                            acc[j] = fmaf(g0, w0[j], acc[j]);
-                            acc[j] = fmaf(g1, w0[CiP + j], acc[j]);
-                            acc[j] = fmaf(g2, w0[2 * CiP + j], acc[j]);
-                            acc[j] = fmaf(g3, w0[3 * CiP + j], acc[j]);
+                        for (int c = 0; c < CV; ++c) {
+                            const float gc = ok ? gv[t][c] : 0.f;
+#pragma unroll
+                            for (int j = 0; j < CIT; ++j) acc[j] = fmaf(gc, w0[c * CiP + j], acc[j]);
                         }
                     }
                 }
@@ -609,7 +621,8 @@ conv_wgrad_small_kernel(Mri3dConvGeom g, const T* __restrict__ x, const T* __res
 // 64-bit flat index per voxel.  Lanes are combined through LDS (double) once per workgroup: same partial layout and final
 // fixed-order sum as above (deterministic).
 // NTAPS = 4, 6 or 8 accumulator slots (the smallest that holds the filter: fewer registers, more resident waves to cover the latency)
-template <typename T, int NTAPS>
+// CIV = input channels per lane: 4 (Ci % 4 == 0) or 1 (Ci = 1: the autoencoder's first conv, (6,1,1) 1 -> 8)
+template <typename T, int NTAPS, int CIV>
 __global__ void __launch_bounds__(256)
 conv_wgrad_quads_kernel(Mri3dConvGeom g, const T* __restrict__ x, const T* __restrict__ dy, float* __restrict__ part,
                         float* __restrict__ bias_part, int QI, int QO, int hch, int CiP, int CoP) {
@@ -619,11 +632,11 @@ conv_wgrad_quads_kernel(Mri3dConvGeom g, const T* __restrict__ x, const T* __res
     const int PV = QI * QO, VL = 256 / PV;           // lanes per voxel, voxel lanes per workgroup (PV divides 256: host)
     const int pq = tid % PV, vl = tid / PV;
     const int iq = pq % QI, oq = pq / QI;
-    float acc[NTAPS][4][4], bsum[4] = {0.f, 0.f, 0.f, 0.f};
+    float acc[NTAPS][CIV][4], bsum[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int t = 0; t < NTAPS; ++t)
 #pragma unroll
-        for (int a = 0; a < 4; ++a)
+        for (int a = 0; a < CIV; ++a)
 #pragma unroll
             for (int b = 0; b < 4; ++b) acc[t][a][b] = 0.f;
     int tkd[NTAPS], tkh[NTAPS], tkw[NTAPS];   // tap coordinates (uniform: scalar registers)
@@ -639,12 +652,12 @@ conv_wgrad_quads_kernel(Mri3dConvGeom g, const T* __restrict__ x, const T* __res
         const int n = nd / g.dout, od = nd - n * g.dout;
         const int h0 = hc * hch, hn = min(hch, g.ho - h0);
         const unsigned inner = (unsigned)hn * g.wo;
-        const T* xn = x + (int64_t)n * g.di * g.hi * g.wi * g.x_ld + 4 * iq;
+        const T* xn = x + (int64_t)n * g.di * g.hi * g.wi * g.x_ld + CIV * iq;
         const T* yn = dy + (((int64_t)nd * g.ho + h0) * g.wo) * g.y_ld + 4 * oq;
         // ALL tap loads of a voxel first, unconditional (clamped address, masked afterwards; taps past the filter re-read tap 0):
         // a load inside `if (ok)` / `if (t < taps)` is followed by its own s_waitcnt and the taps become serial round trips to
         // L2 (7 per voxel: 0.51 ms on the (1,6,1) 8 -> 8 layer at 80x96x160, waves waiting 73 % of their cycles; batched 0.31 ms).
-        auto fetch = [&](unsigned e, float4& gv, float4 (&xv)[NTAPS], unsigned& okm) {
+        auto fetch = [&](unsigned e, float4& gv, float (&xv)[NTAPS][CIV], unsigned& okm) {
             const bool live = e < inner;
             const unsigned ec = live ? e : inner - 1;
             const int ow = ec % g.wo, oh = h0 + ec / g.wo;
@@ -656,11 +669,17 @@ conv_wgrad_quads_kernel(Mri3dConvGeom g, const T* __restrict__ x, const T* __res
                 const bool ok = live && t < taps && (unsigned)id < (unsigned)g.di && (unsigned)ih < (unsigned)g.hi && (unsigned)iw < (unsigned)g.wi;
                 okm |= ok ? (1u << t) : 0u;
                 const int cd = min(max(id, 0), g.di - 1), chh = min(max(ih, 0), g.hi - 1), cw = min(max(iw, 0), g.wi - 1);
-                xv[t] = ldf4(xn + (((int64_t)cd * g.hi + chh) * g.wi + cw) * g.x_ld);
+                const T* xp = xn + (((int64_t)cd * g.hi + chh) * g.wi + cw) * g.x_ld;
+                if constexpr (CIV == 4) {
+                    const float4 q4 = ldf4(xp);
+                    xv[t][0] = q4.x, xv[t][1] = q4.y, xv[t][2] = q4.z, xv[t][3] = q4.w;
+                } else {
+                    xv[t][0] = ldf(xp);
+                }
             }
             if (!live) gv = make_float4(0.f, 0.f, 0.f, 0.f);
         };
-        auto consume = [&](const float4& gv, const float4 (&xv)[NTAPS], unsigned okm) {
+        auto consume = [&](const float4& gv, const float (&xv)[NTAPS][CIV], unsigned okm) {
             const float gq[4] = {gv.x, gv.y, gv.z, gv.w};
             if (iq == 0) {
 #pragma unroll
@@ -669,17 +688,19 @@ conv_wgrad_quads_kernel(Mri3dConvGeom g, const T* __restrict__ x, const T* __res
 #pragma unroll
             for (int t = 0; t < NTAPS; ++t) {
                 const bool ok = (okm >> t) & 1u;
-                const float xq[4] = {ok ? xv[t].x : 0.f, ok ? xv[t].y : 0.f, ok ? xv[t].z : 0.f, ok ? xv[t].w : 0.f};
 #pragma unroll
-                for (int a = 0; a < 4; ++a)
+                for (int a = 0; a < CIV; ++a) {
+                    const float xa = ok ? xv[t][a] : 0.f;
 #pragma unroll
-                    for (int b = 0; b < 4; ++b) acc[t][a][b] = fmaf(xq[a], gq[b], acc[t][a][b]);
+                    for (int b = 0; b < 4; ++b) acc[t][a][b] = fmaf(xa, gq[b], acc[t][a][b]);
+                }
             }
         };
         // (a second register set for the next voxel's loads was measured: with 128 accumulators it pushes the kernel to 256 VGPRs
         //  and 80 spilled SGPRs and is slower, 0.50 vs 0.31 ms; fewer accumulator slots and more waves hide the latency instead)
         for (unsigned e = vl; e < inner; e += VL) {
-            float4 gv, xv[NTAPS];
+            float4 gv;
+            float xv[NTAPS][CIV];
             unsigned okm;
             fetch(e, gv, xv, okm);
             consume(gv, xv, okm);
@@ -689,7 +710,7 @@ conv_wgrad_quads_kernel(Mri3dConvGeom g, const T* __restrict__ x, const T* __res
     for (int t = 0; t < taps; ++t) {
         __syncthreads();
 #pragma unroll
-        for (int a = 0; a < 4; ++a)
+        for (int a = 0; a < CIV; ++a)
 #pragma unroll
             for (int b = 0; b < 4; ++b) {
                 float val = 0.f;
@@ -699,11 +720,11 @@ conv_wgrad_quads_kernel(Mri3dConvGeom g, const T* __restrict__ x, const T* __res
                 red[tid * 16 + a * 4 + b] = val;
             }
         __syncthreads();
-        for (int o = tid; o < PV * 16; o += 256) {
-            const int ab = o % 16, q = o / 16;
+        for (int o = tid; o < PV * (CIV * 4); o += 256) {
+            const int ab = o % (CIV * 4), q = o / (CIV * 4);
             double sdbl = 0.0;
             for (int l = 0; l < VL; ++l) sdbl += (double)red[(l * PV + q) * 16 + ab];
-            const int ci = (q % QI) * 4 + ab / 4, co = (q / QI) * 4 + ab % 4;
+            const int ci = (q % QI) * CIV + ab / 4, co = (q / QI) * 4 + ab % 4;
             if (ci < g.ci && co < g.co) part[(((size_t)blockIdx.x * taps + t) * CiP + ci) * CoP + co] = (float)sdbl;
         }
     }
@@ -1290,6 +1311,9 @@ static bool wgrad_small_ok(const Mri3dConvGeom& g) {
 static bool wgrad_quads_ok(const Mri3dConvGeom& g) {
     const int taps = g.kd * g.kh * g.kw;
     const int pv = (g.ci / 4) * (g.co / 4);
+    if (g.ci == 1)   // one input channel: a lane owns (voxel, co quad)
+        return taps <= kSmTaps && g.co % 4 == 0 && g.co >= 4 && g.co <= 64 && 256 % (g.co / 4) == 0 && g.y_ld % 4 == 0 &&
+               (int64_t)g.ho * g.wo < 0x7fffffffLL && (int64_t)g.n * g.dout * g.ho < 0x7fffffffLL && !cin1_ok(g);
     return taps <= kSmTaps && g.ci % 4 == 0 && g.co % 4 == 0 && g.ci >= 4 && g.co >= 4 && pv <= 64 && 256 % pv == 0 &&
            g.x_ld % 4 == 0 && g.y_ld % 4 == 0 && (int64_t)g.ho * g.wo < 0x7fffffffLL &&
            (int64_t)g.n * g.dout * g.ho < 0x7fffffffLL;
@@ -1297,7 +1321,7 @@ static bool wgrad_quads_ok(const Mri3dConvGeom& g) {
 struct WgradQuadsPlan { int QI, QO, hch, gx, CiP, CoP; size_t part_floats, bias_floats; };
 static WgradQuadsPlan wgrad_quads_plan(const Mri3dConvGeom& g) {
     WgradQuadsPlan p;
-    p.QI = g.ci / 4, p.QO = g.co / 4, p.CiP = g.ci, p.CoP = g.co;
+    p.QI = g.ci == 1 ? 1 : g.ci / 4, p.QO = g.co / 4, p.CiP = g.ci, p.CoP = g.co;
     const int VL = 256 / (p.QI * p.QO);
     // ~16 voxels per lane and slab
     p.hch = (int)std::max<int64_t>(1, std::min<int64_t>(g.ho, (int64_t)16 * VL / std::max(g.wo, 1)));
@@ -1396,16 +1420,18 @@ static void launch_fwd(const Mri3dConvGeom& g, const void* x, const float* wp, c
     dim3 grid((unsigned)std::min<int64_t>(cdiv64(nvox, 256), 8192), CoP / TL);
     bool vec = (g.ci % 4 == 0) && (g.x_ld % 4 == 0) && aligned_vec4(g.dtype, x);
     const int taps = g.kd * g.kh * g.kw;
-    if (vec && taps <= 8 && aligned_vec4(g.dtype, y) && (int64_t)g.ho * g.wo < 0x7fffffffLL && (int64_t)g.n * g.dout * g.ho < 0x7fffffffLL) {
+    if ((vec || g.ci == 1) && taps <= 8 && aligned_vec4(g.dtype, y) && (int64_t)g.ho * g.wo < 0x7fffffffLL && (int64_t)g.n * g.dout * g.ho < 0x7fffffffLL) {
         // few taps: slab walk + batched tap loads (conv_fwd_taps_kernel)
         const int hch = (int)std::max<int64_t>(1, std::min<int64_t>(g.ho, (int64_t)2048 / std::max(g.wo, 1)));
         const int64_t slabs = (int64_t)g.n * g.dout * cdiv(g.ho, hch);
         dim3 tgrid((unsigned)std::min<int64_t>(slabs, 4096), CoP / TL);
         MRI3D_DISPATCH_DTYPE(g.dtype, T, {
-            if (taps <= 4)
-                hipLaunchKernelGGL((conv_fwd_taps_kernel<T, TL, 4>), tgrid, dim3(256), 0, s, g, (const T*)x, wp, bias, (T*)y, CoP, hch);
+            if (vec && taps <= 4)
+                hipLaunchKernelGGL((conv_fwd_taps_kernel<T, TL, 4, 4>), tgrid, dim3(256), 0, s, g, (const T*)x, wp, bias, (T*)y, CoP, hch);
+            else if (vec)
+                hipLaunchKernelGGL((conv_fwd_taps_kernel<T, TL, 8, 4>), tgrid, dim3(256), 0, s, g, (const T*)x, wp, bias, (T*)y, CoP, hch);
             else
-                hipLaunchKernelGGL((conv_fwd_taps_kernel<T, TL, 8>), tgrid, dim3(256), 0, s, g, (const T*)x, wp, bias, (T*)y, CoP, hch);
+                hipLaunchKernelGGL((conv_fwd_taps_kernel<T, TL, 8, 1>), tgrid, dim3(256), 0, s, g, (const T*)x, wp, bias, (T*)y, CoP, hch);
         });
         return;
     }
@@ -1543,16 +1569,18 @@ static void launch_dgrad(const Mri3dConvGeom& g, const void* dy, const float* wp
     bool vec = (g.co % 4 == 0) && (g.y_ld % 4 == 0) && aligned_vec4(g.dtype, dy);
     const int taps = g.kd * g.kh * g.kw;
     const bool unit_stride = g.sd == 1 && g.sh == 1 && g.sw == 1;   // strided layers: the wave-uniform tap sets below are faster (0.29 vs 0.33 ms)
-    if (vec && unit_stride && taps <= 8 && aligned_vec4(g.dtype, dx) && (int64_t)g.hi * g.wi < 0x7fffffffLL && (int64_t)g.n * g.di * g.hi < 0x7fffffffLL) {
+    if ((vec || g.co == 1) && unit_stride && taps <= 8 && aligned_vec4(g.dtype, dx) && (int64_t)g.hi * g.wi < 0x7fffffffLL && (int64_t)g.n * g.di * g.hi < 0x7fffffffLL) {
         // few taps, stride 1: slab walk + batched tap loads (conv_dgrad_taps_kernel)
         const int hch = (int)std::max<int64_t>(1, std::min<int64_t>(g.hi, (int64_t)2048 / std::max(g.wi, 1)));
         const int64_t slabs = (int64_t)g.n * g.di * cdiv(g.hi, hch);
         dim3 tgrid((unsigned)std::min<int64_t>(slabs, 4096), CiP / TL);
         MRI3D_DISPATCH_DTYPE(g.dtype, T, {
-            if (taps <= 4)
-                hipLaunchKernelGGL((conv_dgrad_taps_kernel<T, TL, 4>), tgrid, dim3(256), 0, s, g, (const T*)dy, wp, bias, (T*)dx, CiP, hch);
+            if (vec && taps <= 4)
+                hipLaunchKernelGGL((conv_dgrad_taps_kernel<T, TL, 4, 4>), tgrid, dim3(256), 0, s, g, (const T*)dy, wp, bias, (T*)dx, CiP, hch);
+            else if (vec)
+                hipLaunchKernelGGL((conv_dgrad_taps_kernel<T, TL, 8, 4>), tgrid, dim3(256), 0, s, g, (const T*)dy, wp, bias, (T*)dx, CiP, hch);
             else
-                hipLaunchKernelGGL((conv_dgrad_taps_kernel<T, TL, 8>), tgrid, dim3(256), 0, s, g, (const T*)dy, wp, bias, (T*)dx, CiP, hch);
+                hipLaunchKernelGGL((conv_dgrad_taps_kernel<T, TL, 8, 1>), tgrid, dim3(256), 0, s, g, (const T*)dy, wp, bias, (T*)dx, CiP, hch);
         });
         return;
     }
@@ -1680,20 +1708,21 @@ int conv_generic_wgrad(const Mri3dConvGeom& g, const void* x, const void* dy, fl
                            g.ci, 1, g.ci, 1);
         return check_launch("conv3d_wgrad(co1)");
     }
-    if (wgrad_quads_ok(g) && aligned_vec4(g.dtype, x, dy)) {
+    if (wgrad_quads_ok(g) && aligned_vec4(g.dtype, dy) && (g.ci == 1 || aligned_vec4(g.dtype, x))) {
         WgradQuadsPlan q = wgrad_quads_plan(g);
         const size_t need = (q.part_floats + q.bias_floats) * sizeof(float);
         MRI3D_REQUIRE(ws != nullptr && ws_bytes >= need, MRI3D_EWORKSPACE, "conv3d_wgrad: workspace %zu < %zu", ws_bytes, need);
         float* part = static_cast<float*>(ws);
         float* bias_part = dbias ? part + q.part_floats : nullptr;
         const int taps = g.kd * g.kh * g.kw;
-#define MRI3D_WGQ(NTv)                                                                                                 \
-    hipLaunchKernelGGL((conv_wgrad_quads_kernel<T, NTv>), dim3(q.gx), dim3(256), 0, s, g, (const T*)x, (const T*)dy, part,  \
-                       bias_part, q.QI, q.QO, q.hch, q.CiP, q.CoP)
+#define MRI3D_WGQ(NTv, CIVv)                                                                                           \
+    hipLaunchKernelGGL((conv_wgrad_quads_kernel<T, NTv, CIVv>), dim3(q.gx), dim3(256), 0, s, g, (const T*)x, (const T*)dy,  \
+                       part, bias_part, q.QI, q.QO, q.hch, q.CiP, q.CoP)
         MRI3D_DISPATCH_DTYPE(g.dtype, T, {
-            if (taps <= 4) MRI3D_WGQ(4);
-            else if (taps <= 6) MRI3D_WGQ(6);
-            else MRI3D_WGQ(8);
+            if (g.ci == 1) MRI3D_WGQ(8, 1);
+            else if (taps <= 4) MRI3D_WGQ(4, 4);
+            else if (taps <= 6) MRI3D_WGQ(6, 4);
+            else MRI3D_WGQ(8, 4);
         });
 #undef MRI3D_WGQ
         const int total = g.co * g.ci * taps;
