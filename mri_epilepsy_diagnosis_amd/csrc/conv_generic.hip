@@ -1561,6 +1561,95 @@ conv_dgrad_strided_kernel(Mri3dConvGeom g, const T* __restrict__ dy, const float
     }
 }
 
+// The same wave-per-(n, id, ih, w-residue) decomposition with the valid taps ENUMERATED first (they are wave-uniform: at most NT of
+// them) and, per output-channel quad, their dy loads issued together before the FMAs — in the kernel above every tap's load sits in
+// a run-time loop behind `valid ? load : 0` and gets its own wait (6 serial round trips per voxel of the (1,6,1) stride-2 layer).
+// Slots past the last valid tap re-read slot 0 (cached) and are masked: no branch around a load.
+template <typename T, int CIT, int NT>
+__global__ void __launch_bounds__(64)
+conv_dgrad_strided_taps_kernel(Mri3dConvGeom g, const T* __restrict__ dy, const float* __restrict__ wp,
+                               const float* __restrict__ bias, T* __restrict__ dx, int CiP) {
+    int u = blockIdx.x;
+    const int rw = u % g.sw;
+    u /= g.sw;
+    const int ih = u % g.hi;
+    u /= g.hi;
+    const int id = u % g.di;
+    const int n = u / g.di;
+    const int cit = blockIdx.y * CIT;
+    const int kd0 = (id + g.pd) % g.sd, kh0 = (ih + g.ph) % g.sh, kw0 = (rw + g.pw) % g.sw;
+    // enumerate the taps that reach this row (uniform): dy row base, kw, packed-weight tap index
+    int64_t rowoff[NT];
+    int tkw[NT], ttap[NT];
+    int ntap = 0;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) { rowoff[t] = 0; tkw[t] = kw0; ttap[t] = 0; }
+    for (int kd = kd0; kd < g.kd; kd += g.sd) {
+        const int nd = id + g.pd - kd;
+        if (nd < 0) break;
+        const int od = nd / g.sd;
+        if (od >= g.dout) continue;
+        for (int kh = kh0; kh < g.kh; kh += g.sh) {
+            const int nh = ih + g.ph - kh;
+            if (nh < 0) break;
+            const int oh = nh / g.sh;
+            if (oh >= g.ho) continue;
+            for (int kw = kw0; kw < g.kw; kw += g.sw) {
+#pragma unroll
+                for (int t = 0; t < NT; ++t)
+                    if (t == ntap) {
+                        rowoff[t] = ((((int64_t)n * g.dout + od) * g.ho + oh) * g.wo) * g.y_ld;
+                        tkw[t] = kw;
+                        ttap[t] = (kd * g.kh + kh) * g.kw + kw;
+                    }
+                ++ntap;   // host guarantees <= NT
+            }
+        }
+    }
+    for (int iw = rw + (int)threadIdx.x * g.sw; iw < g.wi; iw += 64 * g.sw) {
+        float acc[CIT];
+#pragma unroll
+        for (int j = 0; j < CIT; ++j) acc[j] = (bias != nullptr && cit + j < g.ci) ? bias[cit + j] : 0.f;
+        int64_t off[NT];
+        unsigned okm = 0;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const int nw = iw + g.pw - tkw[t];
+            const int ow = nw / g.sw;
+            const bool ok = t < ntap && nw >= 0 && ow < g.wo;
+            okm |= ok ? (1u << t) : 0u;
+            off[t] = rowoff[t] + (int64_t)(ok ? ow : 0) * g.y_ld;
+        }
+        for (int co = 0; co < g.co; co += 4) {
+            float4 gv[NT];
+#pragma unroll
+            for (int t = 0; t < NT; ++t) gv[t] = ldf4(dy + off[t] + co);
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                const bool ok = (okm >> t) & 1u;
+                const float g0 = ok ? gv[t].x : 0.f, g1 = ok ? gv[t].y : 0.f, g2 = ok ? gv[t].z : 0.f, g3 = ok ? gv[t].w : 0.f;
+                const float* w0 = wp + ((size_t)ttap[t] * g.co + co) * CiP + cit;
+#pragma unroll
+                for (int j = 0; j < CIT; ++j) {
+                    acc[j] = fmaf(g0, w0[j], acc[j]);
+                    acc[j] = fmaf(g1, w0[CiP + j], acc[j]);
+                    acc[j] = fmaf(g2, w0[2 * CiP + j], acc[j]);
+                    acc[j] = fmaf(g3, w0[3 * CiP + j], acc[j]);
+                }
+            }
+        }
+        T* xp = dx + ((((int64_t)n * g.di + id) * g.hi + ih) * g.wi + iw) * g.x_ld + cit;
+        if (CIT % 4 == 0 && cit + CIT <= g.ci && (g.x_ld & 3) == 0) {
+#pragma unroll
+            for (int j = 0; j < CIT; j += 4) stf4(xp + j, make_float4(acc[j], acc[j + 1], acc[j + 2], acc[j + 3]));
+        } else {
+#pragma unroll
+            for (int j = 0; j < CIT; ++j)
+                if (cit + j < g.ci) stf(xp + j, acc[j]);
+        }
+    }
+}
+
 template <int TL>
 static void launch_dgrad(const Mri3dConvGeom& g, const void* dy, const float* wp, const float* bias, void* dx,
                          int CiP, hipStream_t s) {
@@ -1587,6 +1676,17 @@ static void launch_dgrad(const Mri3dConvGeom& g, const void* dy, const float* wp
     const int64_t rows = (int64_t)g.n * g.di * g.hi * g.sw;
     if ((g.sd > 1 || g.sh > 1 || g.sw > 1) && g.dd == 1 && g.dh == 1 && g.dw == 1 && rows <= 0x7fffffff) {
         dim3 sgrid((unsigned)rows, CiP / TL);
+        // valid taps per input voxel: ceil(k / s) per axis; up to 4 (the separable stride-2 filters: 3) or 8 take the batched kernel
+        const int vt = cdiv(g.kd, g.sd) * cdiv(g.kh, g.sh) * cdiv(g.kw, g.sw);
+        if (vec && vt <= 8 && aligned_vec4(g.dtype, dx)) {
+            MRI3D_DISPATCH_DTYPE(g.dtype, T, {
+                if (vt <= 4)
+                    hipLaunchKernelGGL((conv_dgrad_strided_taps_kernel<T, TL, 4>), sgrid, dim3(64), 0, s, g, (const T*)dy, wp, bias, (T*)dx, CiP);
+                else
+                    hipLaunchKernelGGL((conv_dgrad_strided_taps_kernel<T, TL, 8>), sgrid, dim3(64), 0, s, g, (const T*)dy, wp, bias, (T*)dx, CiP);
+            });
+            return;
+        }
         MRI3D_DISPATCH_DTYPE(g.dtype, T, {
             if (vec)
                 hipLaunchKernelGGL((conv_dgrad_strided_kernel<T, TL, true>), sgrid, dim3(64), 0, s, g, (const T*)dy, wp, bias, (T*)dx, CiP);
