@@ -3,7 +3,7 @@
 #   1. rocprofv3 --kernel-trace --stats of bench.py (fp32 headline, bf16) and of the dominant 48->16 layer
 #      (the layer as the U-Net runs it: conv over cat((skip 16, upsampled 32)) read from two dense tensors, conv_bench --cat 16)
 #   2. --pmc passes (FETCH_SIZE, WRITE_SIZE, SQ busy: never combined with trace domains) of the three passes of that layer, both dtypes
-#   3. the plain bench lines (no profiler)
+#   3. the plain bench lines (no profiler) and the other configurations' step times / per-operator tables (tools/model_bench.py)
 set -o pipefail
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
@@ -21,4 +21,5 @@ bash tools/pmc_conv.sh r02f_bf16_48_16 48 16 160 192 160 2 bf16 "fwd dgrad wgrad
 cd $R
 python3 bench.py > $O/final_bench_f32.json 2> $O/final_bench_f32_optable.txt || exit 1
 python3 bench.py --dtype bf16 > $O/final_bench_bf16.json 2> $O/final_bench_bf16_optable.txt || exit 1
+for m in cfg3ae_graph cfg3_graph m3d_graph cfg3ae m3d cfg5; do TOP=24 python3 tools/model_bench.py $m 2>&1 | grep -v amdgpu.ids >> $O/final_model_bench.txt || exit 1; done
 cat $O/final_bench_f32.json $O/final_bench_bf16.json
