@@ -89,6 +89,38 @@ int main() {
     bad = g; bad.pd = -1;
     EXPECT(mri3d_conv3d_fwd(&bad, P, P, P, P, P, 0, nullptr) == MRI3D_EINVAL);
 
+    // ---- split operands (conv over cat((x, x2))): the support query over a sweep, refusals without a launch
+    {
+        int served = 0;
+        for (int dtype = 0; dtype < 2; ++dtype)
+            for (int ca : {8, 16, 32, 48})
+                for (int cb : {8, 16, 24, 32, 64})
+                    for (int sz : {6, 40, 160}) {
+                        Mri3dConvGeom c = conv(2, sz, sz + 8, sz, ca + cb, 16, 3, 1, 1, 1, dtype, 0, 0);
+                        c.x_ld = ca;
+                        for (int pass = 0; pass < 3; ++pass) served += mri3d_conv3d_cat_supported(&c, ca, cb, pass);
+                        EXPECT(mri3d_conv3d_cat_supported(&c, 0, cb, 0) == 0);          // no first part
+                        EXPECT(mri3d_conv3d_cat_supported(&c, ca + cb, cb, 0) == 0);    // no second part
+                    }
+        EXPECT(served > 0);
+        EXPECT(mri3d_conv3d_cat_supported(nullptr, 16, 32, 0) == 0);
+        Mri3dConvGeom c = conv(2, 160, 192, 160, 48, 16, 3, 1, 1, 1, 0, 0, 0);
+        c.x_ld = 16;
+        EXPECT(mri3d_conv3d_cat_supported(&c, 16, 32, 0) == 1 && mri3d_conv3d_cat_supported(&c, 16, 32, 1) == 1 &&
+               mri3d_conv3d_cat_supported(&c, 16, 32, 2) == 1);
+        EXPECT(mri3d_conv3d_cat_supported(&c, 8, 40, 0) == 0);                         // split not a multiple of 16
+        EXPECT(mri3d_conv3d_fwd_cat(&c, nullptr, P, 16, 32, P, P, P, nullptr, P, 0, nullptr) == MRI3D_EINVAL);
+        EXPECT(mri3d_conv3d_fwd_cat(&c, P, nullptr, 16, 32, P, P, P, nullptr, P, 0, nullptr) == MRI3D_EINVAL);
+        EXPECT(mri3d_conv3d_dgrad_cat(&c, P, P, P, nullptr, 16, 32, P, 0, nullptr) == MRI3D_EINVAL);
+        EXPECT(mri3d_conv3d_wgrad_cat(&c, P, nullptr, 16, 32, P, P, P, P, 0, nullptr) == MRI3D_EINVAL);
+        alignas(16) static char buf2[64];
+        EXPECT(mri3d_conv3d_fwd_cat(&c, buf2, buf2, 8, 40, buf2, buf2, buf2, nullptr, buf2, 0, nullptr) == MRI3D_ENOTSUP);   // bad split
+        EXPECT(mri3d_conv3d_fwd_cat(&c, buf2, buf2 + 4, 16, 32, buf2, buf2, buf2, nullptr, buf2, 0, nullptr) == MRI3D_ENOTSUP);   // misaligned x2
+        EXPECT(mri3d_conv3d_fwd_cat(&c, buf2, buf2, 16, 32, buf2, buf2, buf2, nullptr, buf2, 16, nullptr) == MRI3D_EWORKSPACE);
+        c.x_ld = 8;   // pitch of the first tensor smaller than its channel count
+        EXPECT(mri3d_conv3d_fwd_cat(&c, buf2, buf2, 16, 32, buf2, buf2, buf2, nullptr, buf2, 0, nullptr) == MRI3D_EINVAL);
+    }
+
     // ---- other families: null geometry / null pointers / zero sizes must be refused, workspace queries must not crash
     EXPECT(mri3d_norm_stats(nullptr, P, nullptr, nullptr, nullptr, nullptr, 0.1f, P, 0, nullptr) != MRI3D_OK);
     EXPECT(mri3d_norm_act_fwd(nullptr, P, nullptr, nullptr, nullptr, nullptr, nullptr, P, nullptr) != MRI3D_OK);
