@@ -268,6 +268,10 @@ conv_mfma_fwd2_kernel(const T* __restrict__ x, const float* __restrict__ wp, con
     struct Item { int n, d0, h0, w0, nt0, ch; };
     auto decode = [&](int it) -> Item {
         Item r;
+#if defined(MRI3D_EXPERIMENT_NO_DECODE)   // timing ablation: no divisions (every item is the same interior tile: results are wrong)
+        r.ch = nchunks == 1 ? 0 : it % nchunks; r.nt0 = 0; r.w0 = TW; r.h0 = TH; r.d0 = TD; r.n = 0;
+        return r;
+#endif
         int tile = r_lo + wslot + (it / nchunks) * wper;
         r.ch = it % nchunks;
         r.nt0 = (tile % gy) * NT;
@@ -281,6 +285,40 @@ conv_mfma_fwd2_kernel(const T* __restrict__ x, const float* __restrict__ wp, con
         r.h0 = (tile % tilesH) * TH;
         r.n = tile / tilesH;
 
+        return r;
+    };
+    // A workgroup's tiles are `wper` apart: the next tile's coordinates come from adding wper's mixed-radix digits (N-block, w, d,
+    // h, n) with carries — ~15 scalar instructions instead of decode()'s five run-time divisions (~150).  Measured by ablation
+    // (decode replaced by a constant): the divisions cost 5 % of the fp32 16 -> 16 forward, 12 % of 8 -> 16 and 22 % of the bf16
+    // 16 -> 16 forward, whose tiles are a single chunk (one decode per item).
+    int sdig[5];
+    {
+        int q = wper;
+        sdig[0] = q % gy;
+        q /= gy;
+        sdig[1] = q % tilesW;
+        q /= tilesW;
+        sdig[2] = q % tilesD;
+        q /= tilesD;
+        sdig[3] = q % tilesH;
+        sdig[4] = q / tilesH;
+    }
+    auto advance = [&](const Item& c) -> Item {   // chunk 0 of the tile `wper` after c's
+        Item r;
+        r.ch = 0;
+        int a = c.nt0 / NT + sdig[0];
+        int cy = a >= gy;
+        r.nt0 = (a - (cy ? gy : 0)) * NT;
+        a = c.w0 / TW + sdig[1] + cy;
+        cy = a >= tilesW;
+        r.w0 = (a - (cy ? tilesW : 0)) * TW;
+        a = c.d0 / TD + sdig[2] + cy;
+        cy = a >= tilesD;
+        r.d0 = (a - (cy ? tilesD : 0)) * TD;
+        a = c.h0 / TH + sdig[3] + cy;
+        cy = a >= tilesH;
+        r.h0 = (a - (cy ? tilesH : 0)) * TH;
+        r.n = c.n + sdig[4] + cy;
         return r;
     };
     const unsigned lds_wave = __builtin_amdgcn_readfirstlane((unsigned)(size_t)lds + (unsigned)wv * 1024u);
@@ -360,6 +398,18 @@ conv_mfma_fwd2_kernel(const T* __restrict__ x, const float* __restrict__ wp, con
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) acc[m][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+    float4 bias0[NT];   // the lane's bias quads when the kernel has one N-block (gy == 1: nt0 is always 0)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        bias0[nt] = make_float4(0.f, 0.f, 0.f, 0.f);
+        const int co = nt * 16 + 4 * kq;
+        if (NT == 1 && bias && gy == 1 && co < Nc) {   // (two N-tiles: no registers to spare, the bias is loaded per tile)
+            bias0[nt].x = bias[co];
+            if (co + 1 < Nc) bias0[nt].y = bias[co + 1];
+            if (co + 2 < Nc) bias0[nt].z = bias[co + 2];
+            if (co + 3 < Nc) bias0[nt].w = bias[co + 3];
+        }
+    }
     // A-fragment LDS offsets of a tap group (k-groups 0,1 = pair_tap(tg, 0); k-groups 2,3 = pair_tap(tg, 1), tap 27 = zero weights)
     auto a_off = [&](int tg) -> int {
         const int ta = pair_tap(tg, 0), tb = pair_tap(tg, 1) < 27 ? pair_tap(tg, 1) : 26;
@@ -372,11 +422,10 @@ conv_mfma_fwd2_kernel(const T* __restrict__ x, const float* __restrict__ wp, con
         const float* bufc = lds + (it & 1) * BUF;
         const bool has_next = it + 1 < nitems;
         Item nxt = cur;
-        // the next item is the next chunk of the same tile, or chunk 0 of this workgroup's next tile: only the second case
-        // pays for the five runtime divisions of decode() (a burst of ~150 scalar instructions that the MFMAs do not hide)
+        // the next item is the next chunk of the same tile, or chunk 0 of this workgroup's next tile (advance(): digit adds)
         if (has_next) {
             if (cur.ch + 1 < nchunks) nxt.ch = cur.ch + 1;
-            else nxt = decode(it + 1);
+            else nxt = advance(cur);
         }
         // MRI3D_EXPERIMENT_*: timing ablations of tuning builds (python -m mri_epilepsy_diagnosis_amd.build --variant ...;
         // results are wrong): see DESIGN.md §4.2 for the measured table.
@@ -562,8 +611,9 @@ conv_mfma_fwd2_kernel(const T* __restrict__ x, const float* __restrict__ wp, con
                         T* const yd = second ? y2 : y;
                         const int yld = second ? y2_ld : y_ld, cd = second ? co - nsplit : co;
                         const bool vec = (co + 3 < Nc) && ((yld & 3) == 0);
-                        float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
-                        if (bias) {
+                        float4 bv = bias0[nt];   // one N-tile and one N-block: loaded once per kernel
+                        if (bias && (NT > 1 || gy > 1)) {
+                            bv = make_float4(0.f, 0.f, 0.f, 0.f);
                             bv.x = bias[co];
                             if (co + 1 < Nc) bv.y = bias[co + 1];
                             if (co + 2 < Nc) bv.z = bias[co + 2];
@@ -574,11 +624,15 @@ conv_mfma_fwd2_kernel(const T* __restrict__ x, const float* __restrict__ wp, con
                             asm volatile("" ::"v"(bv.x), "v"(bv.y), "v"(bv.z), "v"(bv.w));
                         }
                         const int ow = cur.w0 + li;
+                        // scalar 64-bit tile base + 32-bit lane / row offsets: the epilogue of a one-chunk tile (every item of the
+                        // 16-channel bf16 layers) otherwise pays three 64-bit vector multiply-adds per output row
+                        T* const ytile = yd + ((((int64_t)cur.n * D + od) * H + cur.h0) * W + cur.w0) * yld;
+                        const unsigned lane_off = (unsigned)(li * yld + cd), row_step = (unsigned)(W * yld);
 #pragma unroll
                         for (int m = 0; m < TH; ++m) {
                             const int oh = cur.h0 + m;
                             if (oh < H && ow < W) {
-                                T* yp = yd + ((((int64_t)cur.n * D + od) * H + oh) * W + ow) * yld + cd;
+                                T* yp = ytile + (lane_off + (unsigned)m * row_step);
                                 const f32x4 a = acc[m][nt];
                                 if (vec) {
                                     stf4(yp, make_float4(a[0] + bv.x, a[1] + bv.y, a[2] + bv.z, a[3] + bv.w));
