@@ -142,6 +142,28 @@ __global__ void pack_w_mfma_n8_kernel(const float* __restrict__ w, WT* __restric
     }
 }
 
+#if defined(MRI3D_EXPERIMENT_STAMPS)   // tuning builds: in-kernel phase stamps of wave 0 of workgroup 0 (cdna_hip_programming.md §7)
+__device__ unsigned long long g_stamps[8];
+__device__ unsigned long long g_block_span[2 * 1024];   // per workgroup of the LAST launch: 100 MHz ticks at loop entry and exit
+extern "C" void mri3d_debug_stamps(unsigned long long* out, int reset) {
+    if (reset) {
+        unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        (void)hipMemcpyToSymbol(HIP_SYMBOL(g_stamps), z, sizeof(z));
+    } else {
+        (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamps), sizeof(unsigned long long) * 8);
+    }
+}
+extern "C" void mri3d_debug_block_spans(unsigned long long* out) {
+    (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_block_span), sizeof(unsigned long long) * 2 * 1024);
+}
+// the phase sums stay in (scalar) registers until the kernel's end: a stamp must not add memory operations or waits to the loop
+#define MRI3D_STAMP(var) unsigned long long var = __builtin_readcyclecounter()
+#define MRI3D_STAMP_ADD(slot, a, b) (stamp_acc[slot] += (b) - (a))
+#else
+#define MRI3D_STAMP(var)
+#define MRI3D_STAMP_ADD(slot, a, b)
+#endif
+
 // ------------------------------------------------------------------ forward / dgrad kernel
 // Persistent workgroups + double-buffered LDS + staging folded into the tap loop.
 //   A first version (round 1, removed) alternated "stage a chunk" and "27 tap groups of MFMA" with a barrier pair in between; the two
@@ -374,6 +396,17 @@ conv_mfma_fwd2_kernel(const T* __restrict__ x, const float* __restrict__ wp, con
     };
     const size_t wstep = (size_t)NTT * 256;
 
+#if defined(MRI3D_EXPERIMENT_DESYNC)   // tuning: delay the second workgroup of every CU by MRI3D_EXPERIMENT_DESYNC x 64 cycles
+    // (measured: no gain on any layer, profiles/r02_workgroup_exit_times.txt — the two workgroups of a CU do not run in lock step)
+    if (blockIdx.x >= (gridDim.x + 1) / 2) {
+        for (int i = 0; i < (MRI3D_EXPERIMENT_DESYNC) / 100; ++i) __builtin_amdgcn_s_sleep(100);
+        __builtin_amdgcn_s_sleep((MRI3D_EXPERIMENT_DESYNC) % 100);
+    }
+#endif
+#if defined(MRI3D_EXPERIMENT_STAMPS)   // the clock the chip holds in this kernel: shader cycles / 100 MHz reference ticks
+    const unsigned long long clk0 = __builtin_amdgcn_s_memtime(), ref0 = __builtin_amdgcn_s_memrealtime();
+    unsigned long long stamp_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#endif
     // prologue: item 0 -> buffer 0 (and, one N-tile: all 14 weight fragments of its chunk)
     Item cur = decode(0);
     f32x4 bqa[NT == 1 ? TG : 1];   // NT = 1: the weight fragments of the WHOLE chunk; fragment tg is re-loaded for the next item
@@ -419,6 +452,7 @@ conv_mfma_fwd2_kernel(const T* __restrict__ x, const float* __restrict__ wp, con
     };
 
     for (int it = 0; it < nitems; ++it) {
+        MRI3D_STAMP(t_item);
         const float* bufc = lds + (it & 1) * BUF;
         const bool has_next = it + 1 < nitems;
         Item nxt = cur;
@@ -599,6 +633,8 @@ conv_mfma_fwd2_kernel(const T* __restrict__ x, const float* __restrict__ wp, con
         }
         }
 
+        MRI3D_STAMP(t_mfma);
+        MRI3D_STAMP_ADD(0, t_item, t_mfma);
         if (cur.ch == nchunks - 1) {
             // epilogue: lane holds channels 4*kq..4*kq+3 of voxel li of every 16x16 tile
             const int od = cur.d0 + wv;
@@ -684,13 +720,34 @@ conv_mfma_fwd2_kernel(const T* __restrict__ x, const float* __restrict__ wp, con
         }
         // The DMA pieces of the next item are OLDER than the >= 12 weight loads issued after them in this iteration, and VMEM
         // returns in order: at most that many operations outstanding means every piece has landed in LDS.
+        MRI3D_STAMP(t_epi);
+        MRI3D_STAMP_ADD(1, t_mfma, t_epi);
         constexpr int kYounger = N8 ? 2 : 6;   // VMEM operations certainly issued after the last DMA piece (weight reloads)
         asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kYounger) : "memory");
+        MRI3D_STAMP(t_wait);
+        MRI3D_STAMP_ADD(2, t_epi, t_wait);
 #if !defined(MRI3D_EXPERIMENT_NO_CHUNK_BARRIER)   // tuning builds only: timing ablation, results are wrong without it
         __syncthreads();  // buffer (it+1)&1 is complete; buffer it&1 may be overwritten from the next iteration on
 #endif
+        MRI3D_STAMP(t_bar);
+        MRI3D_STAMP_ADD(3, t_wait, t_bar);
+        MRI3D_STAMP_ADD(4, t_item, t_bar);
+        MRI3D_STAMP_ADD(5, 0ull, 1ull);
         cur = nxt;
     }
+#if defined(MRI3D_EXPERIMENT_STAMPS)
+    {
+        const unsigned long long clk1 = __builtin_amdgcn_s_memtime(), ref1 = __builtin_amdgcn_s_memrealtime();
+        MRI3D_STAMP_ADD(6, clk0, clk1);
+        MRI3D_STAMP_ADD(7, ref0, ref1);
+        if (blockIdx.x == 0 && threadIdx.x == 0)
+            for (int i = 0; i < 8; ++i) g_stamps[i] += stamp_acc[i];
+        if (threadIdx.x == 0 && blockIdx.x < 1024) {
+            g_block_span[2 * blockIdx.x] = ref0;
+            g_block_span[2 * blockIdx.x + 1] = ref1;
+        }
+    }
+#endif
     if constexpr (STATS) {   // the loop ended with a barrier: combine the four waves in a fixed order, one partial per workgroup
         for (int i = tid; i < Nc * 2; i += 256) {
             const int c2 = i;   // (channel, stat) pair; LDS rows are NTT*16 channels wide

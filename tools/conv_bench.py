@@ -24,7 +24,7 @@ def main():
         del sys.argv[i:i + 2]
     ci, co, d, h, w = (int(a) for a in sys.argv[1:6])
     n = int(sys.argv[6]) if len(sys.argv) > 6 else 2
-    reps = int(sys.argv[7]) if len(sys.argv) > 7 else 10
+    reps = int(sys.argv[7]) if len(sys.argv) > 7 else 10   # >= 2 s of back-to-back launches for a settled clock: reps ~ 2000
     passes = sys.argv[8].split(",") if len(sys.argv) > 8 else ["fwd", "dgrad", "wgrad"]
     dt = torch.bfloat16 if (len(sys.argv) > 9 and sys.argv[9] == "bf16") else torch.float32
     dev = torch.device("cuda")
@@ -63,6 +63,9 @@ def main():
         fn = fns[p]
         fn(); fn()
         torch.cuda.synchronize()
+        stamps = getattr(_lib.lib(), "mri3d_debug_stamps", None) if p != "wgrad" else None   # -DMRI3D_EXPERIMENT_STAMPS builds only
+        if stamps is not None:
+            stamps(None, 1)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         for _ in range(reps):
@@ -72,6 +75,26 @@ def main():
         ms = e0.elapsed_time(e1) / reps
         print("%-5s %s->%d @%dx%dx%d n%d %s: %.3f ms  %.1f TFLOP/s" % (p, ("%d+%d" % (split, ci - split)) if split else str(ci), co, d, h, w, n, str(dt)[6:], ms, flops / ms / 1e9),
               flush=True)
+        if stamps is not None:   # wave 0 of workgroup 0: clocks per work item in the chunk loop / epilogue / DMA wait / barrier
+            buf = (ctypes.c_ulonglong * 8)()
+            stamps(buf, 0)
+            items = max(1, buf[5])
+            print("      stamps/item (%d items): mfma %.0f  epilogue %.0f  dma-wait %.0f  barrier %.0f  total %.0f clk"
+                  % (items // reps, buf[0] / items, buf[1] / items, buf[2] / items, buf[3] / items, buf[4] / items), flush=True)
+            spans = getattr(_lib.lib(), "mri3d_debug_block_spans", None)
+            if spans is not None:   # when do the workgroups of the last launch enter and leave their tile loop (100 MHz ticks)?
+                import numpy as np
+                sb = (ctypes.c_ulonglong * 2048)()
+                spans(sb)
+                a = np.array(sb[:], dtype=np.int64).reshape(1024, 2)[:512]
+                t0 = a[:, 0].min()
+                st, en = (a[:, 0] - t0) / 100.0, (a[:, 1] - t0) / 100.0
+                print("      workgroup loop entry (us after the first): median %.1f max %.1f;  exit: min %.1f  p10 %.1f  median %.1f  p90 %.1f  max %.1f"
+                      % (np.median(st), st.max(), en.min(), np.percentile(en, 10), np.median(en), np.percentile(en, 90), en.max()))
+                print("      exit by XCD (median us): " + " ".join("%.1f" % np.median(en[k::8]) for k in range(8))
+                      + ";  loop length by XCD: " + " ".join("%.1f" % np.median((en - st)[k::8]) for k in range(8)), flush=True)
+            print("      in-kernel clock %.2f GHz (s_memtime / s_memrealtime x 100 MHz, MI355X_MICROARCH.md DVFS item 6); MFMA-pipe cycles per"
+                  " CU-cycle at that clock = TFLOP/s / (%.1f x clock/2.4)" % (buf[6] / max(1, buf[7]) * 0.1, 157.3 if dt == torch.float32 else 2516.6), flush=True)
 
 
 if __name__ == "__main__":
