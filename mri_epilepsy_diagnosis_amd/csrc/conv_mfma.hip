@@ -1938,12 +1938,37 @@ __device__ __forceinline__ float4 ldg4(const float* p) {
     return make_float4(v[0], v[1], v[2], v[3]);
 }
 
-template <bool BIAS>
+//
+// Eight-channel operands (Modified3DUNet's first level, modified_3dunet.py:33-55: 8 -> 8 twice, 16 -> 8) would leave half of a
+// 16-row / 16-column operand empty.  CO8 (Co == 8): columns 8..15 of the dY operand carry the SAME eight channels for the next kw
+// tap — lane li reads channel li & 7 and selects dY[u+1] (kw 0, columns 0..7) or dY[u] (kw 1, columns 8..15); a second operand
+// carries kw 2: two MFMAs per (kd, kh) and k-step instead of three.  CI8 (Ci == 8): rows 8..15 of the X operand carry the same
+// eight channels for the next (kd, kh) row pair — (kd,kh) = 2p + (li >> 3), five fragments instead of nine.  8 -> 8 then needs
+// 10 MFMAs per k-step instead of the 27 of a half-empty 16 x 16 tile (and of the 14 of the older v3 kernel); the unused halves of
+// the last pair / the kw-2 operand are duplicates that wgrad_mfma_reduce_kernel drops (accumulator -> tap map: wg6_tap()).
+__host__ __device__ constexpr int wg6_groups(bool ci8, bool co8) { return (ci8 ? 5 : 9) * (co8 ? 2 : 3); }
+// tap of element (row, col) of accumulator tg, or -1 (duplicate / padding)
+__host__ __device__ inline int wg6_tap(bool ci8, bool co8, int tg, int row, int col) {
+    const int nb = co8 ? 2 : 3, pa = tg / nb, q = tg % nb;
+    int kdh = pa, kw = q;
+    if (ci8) {
+        kdh = 2 * pa + (row >> 3);
+        if (kdh > 8) return -1;
+    }
+    if (co8) {
+        kw = q == 0 ? (col >> 3) : 2;
+        if (q == 1 && (col >> 3)) return -1;
+    }
+    return kdh * 3 + kw;
+}
+
+template <bool BIAS, bool CI8 = false, bool CO8 = false>
 __global__ void __launch_bounds__(256, 2)
 conv_mfma_wgrad6_kernel(const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ part, int N, int D,
                         int H, int W, int Ci, int x_ld, int Co, int y_ld, int tilesD, int tilesH, int tilesW, int ntiles,
                         const float* __restrict__ x2, int x2_ld, int ksplit) {
-    constexpr int TG = 27, TGA = TG + (BIAS ? 1 : 0);
+    constexpr int NA = CI8 ? 5 : 9, NB = CO8 ? 2 : 3;
+    constexpr int TG = NA * NB, TGA = TG + (BIAS ? 1 : 0);
     // conv over cat((x, x2)): this workgroup's 16-channel ci-tile lives in ONE of the two tensors — rebind x / pitch / channel origin
     int xc0 = (int)blockIdx.y * 16;
     if (x2 != nullptr && xc0 >= ksplit) { x = x2; x_ld = x2_ld; xc0 -= ksplit; }
@@ -1966,32 +1991,53 @@ conv_mfma_wgrad6_kernel(const float* __restrict__ x, const float* __restrict__ d
     const int h_q = tid & 3, h_side = (tid >> 2) & 1, h_row = tid >> 3;
     const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
     const int orow0 = wv * (BYR / 4);   // first of the wave's three output rows (same d-plane, consecutive h)
-    const char* const xrow0 = xs + (((orow0 / BTH) * BHH + orow0 % BTH) * 16 + li) * DLS + 16 * rot_slot(kq, li);   // tap (kd,kh) = (0,0)
-    const int yline0 = orow0 * 16 + li;
-    const char* const yrow0 = ys + yline0 * DLS + 16 * rot_slot(kq, li);
+    const int ar = CI8 ? (li & 7) : li, ahs = CI8 ? (li >> 3) : 0;   // X operand row li: channel, (kd, kh) half
+    const int bc = CO8 ? (li & 7) : li, bhs = CO8 ? (li >> 3) : 0;   // dY operand column li: channel, kw half
+    const char* const xrow0 = xs + (((orow0 / BTH) * BHH + orow0 % BTH) * 16 + ar) * DLS + 16 * rot_slot(kq, ar);   // tap (kd,kh) = (0,0)
+    int aoff[NA];   // CI8: the lane's line offset of pair p, (kd, kh) = 2p + ahs (the ninth has no partner: a duplicate)
+#pragma unroll
+    for (int pa = 0; pa < NA; ++pa) {
+        const int kdh = CI8 ? (2 * pa + ahs < 9 ? 2 * pa + ahs : 8) : pa;
+        aoff[pa] = ((kdh / 3) * BHH + kdh % 3) * 16 * DLS;
+    }
+    const int yline0 = orow0 * 16 + bc;
+    const char* const yrow0 = ys + yline0 * DLS + 16 * rot_slot(kq, bc);
     // voxel before / after the lane's four: last float of the previous / first float of the next k-group's slot, or the W halo
-    const char* const ypl0 = kq == 0 ? yh + yline0 * 8 : ys + yline0 * DLS + 16 * rot_slot(kq - 1, li) + 12;
-    const char* const ynr0 = kq == 3 ? yh + yline0 * 8 + 4 : ys + yline0 * DLS + 16 * rot_slot(kq + 1, li);
+    const char* const ypl0 = kq == 0 ? yh + yline0 * 8 : ys + yline0 * DLS + 16 * rot_slot(kq - 1, bc) + 12;
+    const char* const ynr0 = kq == 3 ? yh + yline0 * 8 + 4 : ys + yline0 * DLS + 16 * rot_slot(kq + 1, bc);
     const int pl_step = kq == 0 ? 16 * 8 : 16 * DLS, nr_step = kq == 3 ? 16 * 8 : 16 * DLS;
 
     // next tile's pieces: fetched into registers while the current tile is multiplied (HBM/L2 latency hidden), written to
     // the single LDS tile between two barriers after it
     float4 vx[2][4], vh, vy[4];
     // Per-lane element offsets of its pieces from the tile's origin voxels, computed once: a piece's address is then a
-    // wave-uniform tile base + a 32-bit lane offset (+ j voxels), with no per-tile vector multiplies or 64-bit mads.
-    // X origin = voxel (d0-1, h0-1, w0), dY origin = (d0, h0, w0); out-of-volume pieces read the tile's first output voxel.
+    // wave-uniform tile base + a 32-bit lane offset, with no per-tile vector multiplies or 64-bit mads.
+    // X origin = voxel (d0-1, h0-1, w0), dY origin = (d0, h0, w0).  Lanes without a piece (no such channel quad / row) read a
+    // duplicate of an existing one and do not store it: EVERY lane issues the same 13 loads, unconditionally.
+    // Two forms of the staging.  The 16-channel kernel keeps round 1's (load_tile_base): an interior tile is a scalar base plus
+    // the lane offsets, wait-free; only border tiles (29 % at 160x192x160) select on loaded values, which makes hipcc wait for the
+    // loads on the spot.  The eight-channel variants (load_tile_8) issue the same 13 loads in every lane, unconditionally —
+    // lanes without a piece read a duplicate — and never look at a loaded value: out-of-volume pieces read a safe in-volume voxel,
+    // their validity goes into a bit mask, and store_tile_8() zeroes them after the MFMAs (a load under a divergent `if` made
+    // hipcc wait inside the interior path of these variants).  The same form for the 16-channel kernel measured 8 % SLOWER on the
+    // 48 -> 16 layer (3.35 -> 3.63 ms): its per-lane 64-bit address arithmetic does not hide behind fp32 MFMAs.
     unsigned xrel[2], yrel;
+    const int xq = CI8 ? (s_q & 1) : s_q, yq = CO8 ? (s_q & 1) : s_q, hq = CO8 ? (h_q & 1) : h_q;   // an existing channel quad
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
         const int row = s_row + 16 * u;
-        xrel[u] = (unsigned)((((row / BHH) * H + row % BHH) * W + 4 * s_wg) * x_ld + 4 * s_q);
+        xrel[u] = (unsigned)((((row / BHH) * H + row % BHH) * W + 4 * s_wg) * x_ld + 4 * xq);
     }
-    const unsigned xsafe = (unsigned)(((H + 1) * W) * x_ld);
-    yrel = (unsigned)((((s_row / BTH) * H + s_row % BTH) * W + 4 * s_wg) * y_ld + 4 * s_q);
+    const unsigned xsafe = (unsigned)(((H + 1) * W) * x_ld);   // the tile's first output voxel (always in the volume)
+    const bool yrow_ok = tid < BYR * 16, hrow_ok = tid < BYR * 8;
+    yrel = yrow_ok ? (unsigned)((((s_row / BTH) * H + s_row % BTH) * W + 4 * s_wg) * y_ld + 4 * yq) : 0u;
     // halo voxel relative to (d0, h0, w0 - 1): never negative
-    const unsigned hrel = (unsigned)((((h_row / BTH) * H + h_row % BTH) * W + (h_side ? FTW + 1 : 0)) * y_ld + 4 * h_q);
-    const bool co_full = cob * 16 + 16 <= Co;
-    auto load_tile = [&](int tile) {
+    const unsigned hrel = hrow_ok ? (unsigned)((((h_row / BTH) * H + h_row % BTH) * W + (h_side ? FTW + 1 : 0)) * y_ld + 4 * hq) : (unsigned)y_ld;
+    const bool co_full = CO8 || cob * 16 + 16 <= Co;
+    const bool xon = !CI8 || s_q < 2, yon = yrow_ok && (!CO8 || s_q < 2), hon = hrow_ok && (!CO8 || h_q < 2);   // lanes that store
+    unsigned okbits = ~0u;   // of the tile in the registers: bit 4u+j X piece (u, j), bit 8+j dY piece j, bit 12 the halo voxel
+    bool border = false;     // ... and whether any lane has a zero bit (wave-uniform)
+    auto load_tile_base = [&](int tile) {   // both operands 16 channels wide: the round-1 form, at the register limit as it is
         const int w0 = (tile % tilesW) * FTW;
         tile /= tilesW;
         const int d0 = (tile % tilesD) * BTD;
@@ -2050,7 +2096,7 @@ conv_mfma_wgrad6_kernel(const float* __restrict__ x, const float* __restrict__ d
             vh = ok ? t : zero4;
         }
     };
-    auto store_tile = [&]() {
+    auto store_tile_base = [&]() {
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
             char* dst = xs + ((s_row + 16 * u) * 16 + 4 * s_q) * DLS + 16 * rot_slot(s_wg, 4 * s_q);   // 4 channels share a rotation
@@ -2075,13 +2121,129 @@ conv_mfma_wgrad6_kernel(const float* __restrict__ x, const float* __restrict__ d
         }
     };
 
+    auto load_tile_8 = [&](int tile) {
+        const int w0 = (tile % tilesW) * FTW;
+        tile /= tilesW;
+        const int d0 = (tile % tilesD) * BTD;
+        tile /= tilesD;
+        const int h0 = (tile % tilesH) * BTH;
+        const int n = tile / tilesH;
+        // wave-uniform bases; the X base may point before the tensor (d0 = 0 ...) and is only dereferenced at valid offsets
+        const float* xb = x + ((((int64_t)n * D + d0 - 1) * H + h0 - 1) * W + w0) * x_ld + xc0;
+        const float* yb = dy + ((((int64_t)n * D + d0) * H + h0) * W + w0) * y_ld + cob * 16;
+        unsigned xo[2][4], yo[4], ho = hrel, bits = ~0u;
+        // Interior tile (the common case; wave-uniform test on scalars): every piece is in the volume.  The general path costs
+        // ~300 integer instructions per tile against the tile's 336 MFMAs per wave, and none of them hides behind the fp32 MFMA.
+        const bool interior = d0 >= 1 && d0 + BTD < D && h0 >= 1 && h0 + BTH < H && w0 >= 1 && w0 + FTW < W && co_full;
+        if (interior) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                xo[0][j] = xrel[0] + (unsigned)(j * x_ld);
+                xo[1][j] = xrel[1] + (unsigned)(j * x_ld);
+                yo[j] = yrel + (unsigned)(j * y_ld);
+            }
+        } else {
+            bits = 0u;
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {   // ---- X
+                const int row = s_row + 16 * u;
+                const int gd = d0 - 1 + row / BHH, gh = h0 - 1 + row % BHH;
+                const bool rok = (unsigned)gd < (unsigned)D && (unsigned)gh < (unsigned)H;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const bool ok = rok && w0 + 4 * s_wg + j < W;
+                    xo[u][j] = ok ? xrel[u] + (unsigned)(j * x_ld) : xsafe;
+                    bits |= ok ? 1u << (4 * u + j) : 0u;
+                }
+            }
+            {   // ---- dY
+                const int gd = d0 + s_row / BTH, gh = h0 + s_row % BTH;
+                const bool rok = yrow_ok && gd < D && gh < H && cob * 16 + 4 * s_q < Co;       // host guarantees Co % 4 == 0
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const bool ok = rok && w0 + 4 * s_wg + j < W;
+                    yo[j] = ok ? yrel + (unsigned)(j * y_ld) : 0u;
+                    bits |= ok ? 1u << (8 + j) : 0u;
+                }
+            }
+            {   // ---- dY W-halo voxels w0 - 1 / w0 + 16
+                const int gd = d0 + h_row / BTH, gh = h0 + h_row % BTH, gw = h_side ? w0 + FTW : w0 - 1;
+                const bool ok = hrow_ok && gd < D && gh < H && (unsigned)gw < (unsigned)W && cob * 16 + 4 * h_q < Co;
+                ho = ok ? hrel : (unsigned)y_ld;
+                bits |= ok ? 1u << 12 : 0u;
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            vx[0][j] = ldg4(xb + xo[0][j]);
+            vx[1][j] = ldg4(xb + xo[1][j]);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) vy[j] = ldg4(yb + yo[j]);
+        vh = ldg4(yb - y_ld + ho);
+        okbits = bits;
+        border = !interior;
+    };
+    auto store_tile_8 = [&]() {
+        if (border) {   // wave-uniform; the loads landed long ago (a tile of MFMAs lies between load_tile and store_tile)
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (!((okbits >> (4 * u + j)) & 1u)) vx[u][j] = zero4;
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (!((okbits >> (8 + j)) & 1u)) vy[j] = zero4;
+            if (!((okbits >> 12) & 1u)) vh = zero4;
+        }
+        if (xon) {
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                char* dst = xs + ((s_row + 16 * u) * 16 + 4 * s_q) * DLS + 16 * rot_slot(s_wg, 4 * s_q);   // 4 channels share a rotation
+                *reinterpret_cast<float4*>(dst) = make_float4(vx[u][0].x, vx[u][1].x, vx[u][2].x, vx[u][3].x);
+                *reinterpret_cast<float4*>(dst + DLS) = make_float4(vx[u][0].y, vx[u][1].y, vx[u][2].y, vx[u][3].y);
+                *reinterpret_cast<float4*>(dst + 2 * DLS) = make_float4(vx[u][0].z, vx[u][1].z, vx[u][2].z, vx[u][3].z);
+                *reinterpret_cast<float4*>(dst + 3 * DLS) = make_float4(vx[u][0].w, vx[u][1].w, vx[u][2].w, vx[u][3].w);
+            }
+        }
+        if (yon) {
+            char* dst = ys + (s_row * 16 + 4 * s_q) * DLS + 16 * rot_slot(s_wg, 4 * s_q);
+            *reinterpret_cast<float4*>(dst) = make_float4(vy[0].x, vy[1].x, vy[2].x, vy[3].x);
+            *reinterpret_cast<float4*>(dst + DLS) = make_float4(vy[0].y, vy[1].y, vy[2].y, vy[3].y);
+            *reinterpret_cast<float4*>(dst + 2 * DLS) = make_float4(vy[0].z, vy[1].z, vy[2].z, vy[3].z);
+            *reinterpret_cast<float4*>(dst + 3 * DLS) = make_float4(vy[0].w, vy[1].w, vy[2].w, vy[3].w);
+        }
+        if (hon) {
+            char* dst = yh + (h_row * 16 + 4 * h_q) * 8 + 4 * h_side;
+            *reinterpret_cast<float*>(dst) = vh.x;
+            *reinterpret_cast<float*>(dst + 8) = vh.y;
+            *reinterpret_cast<float*>(dst + 16) = vh.z;
+            *reinterpret_cast<float*>(dst + 24) = vh.w;
+        }
+    };
+
+    auto load_tile = [&](int tile) {
+        if constexpr (CI8 || CO8) load_tile_8(tile);
+        else load_tile_base(tile);
+    };
+    auto store_tile = [&]() {
+        if constexpr (CI8 || CO8) store_tile_8();
+        else store_tile_base();
+    };
+
     const TileWalk tw = tile_walk(ntiles);
     if (tw.count > 0) load_tile(tw.first);
     for (int k = 0; k < tw.count; ++k) {
+#if !defined(MRI3D_EXPERIMENT_WG6_NOSTORE)   // tuning builds: the LDS tile is written once
         __syncthreads();   // the previous tile's MFMAs are done with the LDS tile
         store_tile();
         __syncthreads();
-        if (k + 1 < tw.count) load_tile(tw.first + (k + 1) * tw.stride);
+#else
+        if (k == 0) { store_tile(); __syncthreads(); }
+#endif
+#if !defined(MRI3D_EXPERIMENT_WG6_NOLOAD)   // tuning builds: every tile re-uses the first tile's registers (no global loads in the loop)
+        load_tile(tw.first + (k + 1 < tw.count ? k + 1 : k) * tw.stride);   // (the last iteration re-reads its own tile: no branch)
+#endif
         __builtin_amdgcn_sched_barrier(0);
 
         // ---- 3 output rows per wave x 9 (kd, kh) x 3 kw x 4 k-steps
@@ -2101,16 +2263,24 @@ conv_mfma_wgrad6_kernel(const float* __restrict__ x, const float* __restrict__ d
 #pragma unroll
                 for (int j = 0; j < 4; ++j) acc[TG] = __builtin_amdgcn_mfma_f32_16x16x4f32(1.0f, b1[j], acc[TG], 0, 0, 0);
             }
+            float bp[4];   // CO8: kw 0 (columns 0..7) | kw 1 (columns 8..15)
 #pragma unroll
-            for (int kdh = 0; kdh < 9; ++kdh) {
-                const int lrow = ((kdh / 3) * BHH + kdh % 3) * 16;   // compile-time after unrolling
-                const float4 g = *reinterpret_cast<const float4*>(xrow + lrow * DLS);
+            for (int j = 0; j < 4; ++j) bp[j] = bhs ? b1[j] : b0[j];
+#pragma unroll
+            for (int pa = 0; pa < NA; ++pa) {
+                // the line offset is a compile-time constant after unrolling (CI8: one per-lane register per pair)
+                const float4 g = *reinterpret_cast<const float4*>(xrow + (CI8 ? aoff[pa] : ((pa / 3) * BHH + pa % 3) * 16 * DLS));
                 const float a[4] = {g.x, g.y, g.z, g.w};
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    acc[kdh * 3 + 0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j], b0[j], acc[kdh * 3 + 0], 0, 0, 0);
-                    acc[kdh * 3 + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j], b1[j], acc[kdh * 3 + 1], 0, 0, 0);
-                    acc[kdh * 3 + 2] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j], b2[j], acc[kdh * 3 + 2], 0, 0, 0);
+                    if constexpr (CO8) {
+                        acc[pa * 2 + 0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j], bp[j], acc[pa * 2 + 0], 0, 0, 0);
+                        acc[pa * 2 + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j], b2[j], acc[pa * 2 + 1], 0, 0, 0);
+                    } else {
+                        acc[pa * 3 + 0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j], b0[j], acc[pa * 3 + 0], 0, 0, 0);
+                        acc[pa * 3 + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j], b1[j], acc[pa * 3 + 1], 0, 0, 0);
+                        acc[pa * 3 + 2] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j], b2[j], acc[pa * 3 + 2], 0, 0, 0);
+                    }
                 }
             }
         }
@@ -2141,7 +2311,7 @@ conv_mfma_wgrad6_kernel(const float* __restrict__ x, const float* __restrict__ d
 // (Co, Ci, 3,3,3) layout.
 __global__ void __launch_bounds__(256)
 wgrad_mfma_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw, float* __restrict__ dbias, int P,
-                         int CIT, int COB, int CK, int TG, int TGA, int Ci, int Co) {
+                         int CIT, int COB, int CK, int TG, int TGA, int Ci, int Co, int mode8) {
     __shared__ double red[256];
     const int el = threadIdx.x & 63, ql = threadIdx.x >> 6;
     const int nelem = CIT * COB * TGA * 256;
@@ -2169,21 +2339,27 @@ wgrad_mfma_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw,
     const int tg = t % TGA;
     t /= TGA;
     const int cob = t % COB, cit = t / COB;
-    const int co = cob * 16 + col;
+    // mode8 (v6 with eight-channel operands; bit 0: Ci == 8, bit 1: Co == 8): rows / columns 8..15 repeat the channels for another tap
+    const bool ci8 = mode8 & 1, co8 = mode8 & 2;
+    const int co = co8 ? (col & 7) : cob * 16 + col;
     if (co >= Co) return;
     if (tg == TG) {  // bias accumulator (all rows equal): take row 0 of the first ci tile
-        if (dbias != nullptr && cit == 0 && row == 0) dbias[co] = (float)s;
+        if (dbias != nullptr && cit == 0 && row == 0 && !(co8 && col >= 8)) dbias[co] = (float)s;
         return;
     }
     int ci, tap;
-    if (CK == 16) { ci = cit * 16 + row; tap = tg; }
+    if (mode8) {
+        ci = ci8 ? (row & 7) : cit * 16 + row;
+        tap = wg6_tap(ci8, co8, tg, row, col);
+        if (tap < 0) return;
+    } else if (CK == 16) { ci = cit * 16 + row; tap = tg; }
     else if (CK == 8) { ci = cit * 8 + (row & 7); tap = 2 * tg + (row >> 3); }
     else { ci = cit; tap = 16 * tg + row; }
     if (tap < 27 && ci < Ci) dw[((size_t)co * Ci + ci) * 27 + tap] = (float)s;
 }
 
 struct MfmaWgradPlan {
-    int CK, CIT, COB, TG, P, tilesD, tilesH, tilesW, ntiles, v2;
+    int CK, CIT, COB, TG, P, tilesD, tilesH, tilesW, ntiles, v2, mode8;
     size_t part_floats, smem;
 };
 
@@ -2198,7 +2374,15 @@ static bool mfma_wgrad_plan(const Mri3dConvGeom& g, MfmaWgradPlan& p) {
     p.v2 = (g.ci % 8 == 0 && g.co % 4 == 0 && g.y_ld % 4 == 0) ? (g.ci % 16 == 0 ? 2 : 1) : 0;
     if (g.dtype == MRI3D_BF16 && g.ci % 8 == 0 && g.co % 8 == 0 && g.x_ld % 8 == 0 && g.y_ld % 8 == 0) p.v2 = 3;
     if (p.v2 == 2 && g.dtype == MRI3D_F32) p.v2 = 4;
+    // v6 with eight-channel operands: 16k -> 8 (dY columns paired over kw) and 8 -> 8 (X rows paired over (kd, kh) as well);
+    // 8 -> 16 stays on v3 (same MFMA count either way)
+    p.mode8 = 0;
+    if (g.dtype == MRI3D_F32 && g.co == 8 && g.y_ld % 4 == 0 && g.x_ld % 4 == 0 && (g.ci % 16 == 0 || g.ci == 8)) {
+        p.v2 = 4;
+        p.mode8 = 2 | (g.ci == 8 ? 1 : 0);
+    }
     if (p.v2 == 3) p.CK = 16;
+    else if (p.mode8) p.CK = 16;
     else if (p.v2 != 0 && g.ci % 16 == 0) p.CK = 16;
     else if (p.v2 != 0) p.CK = 8;
     else if (g.ci == 1) {
@@ -2210,7 +2394,7 @@ static bool mfma_wgrad_plan(const Mri3dConvGeom& g, MfmaWgradPlan& p) {
     if (p.CK >= 4 && g.x_ld % 4 != 0) return false;
     p.CIT = cdiv(g.ci, p.CK);
     p.COB = cdiv(g.co, 16);
-    p.TG = wg_tap_groups(p.CK);
+    p.TG = p.mode8 ? wg6_groups(p.mode8 & 1, p.mode8 & 2) : wg_tap_groups(p.CK);
     p.tilesD = cdiv(g.di, p.v2 >= 3 ? BTD : WTD);
     p.tilesH = cdiv(g.hi, p.v2 >= 3 ? BTH : (p.v2 == 2 ? V4TH : WTH));
     p.tilesW = cdiv(g.wi, p.v2 == 3 ? BTW : (p.v2 == 4 ? FTW : WTW));
@@ -2316,15 +2500,18 @@ static void run_mfma_wgrad(const MfmaWgradPlan& p, const Mri3dConvGeom& g, const
         if constexpr (sizeof(T) == 4) {
             dim3 grid(p.P, p.CIT, p.COB);
 #define MRI3D_WG6(Bv)                                                                                                 \
+    if (p.mode8 == 3) MRI3D_WG6M(Bv, true, true) else if (p.mode8 == 2) MRI3D_WG6M(Bv, false, true) else MRI3D_WG6M(Bv, false, false)
+#define MRI3D_WG6M(Bv, I8, O8)                                                                                        \
     {                                                                                                                 \
-        auto kern = conv_mfma_wgrad6_kernel<Bv>;                                                                      \
+        auto kern = conv_mfma_wgrad6_kernel<Bv, I8, O8>;                                                              \
         MRI3D_SET_SMEM_ONCE(kern, p.smem);                                                                            \
         hipLaunchKernelGGL(kern, grid, dim3(256), p.smem, s, x, dy, part, g.n, g.di, g.hi, g.wi, g.ci, g.x_ld, g.co,  \
                            g.y_ld, p.tilesD, p.tilesH, p.tilesW, p.ntiles, (const float*)sp.second, sp.second_ld,     \
                            sp.split);                                                                                 \
     }
-            if (bias) MRI3D_WG6(true) else MRI3D_WG6(false)
+            if (bias) { MRI3D_WG6(true) } else { MRI3D_WG6(false) }
 #undef MRI3D_WG6
+#undef MRI3D_WG6M
         }
     } else if (p.v2 == 2) {
       if constexpr (sizeof(T) == 2) {   // fp32 tensors with Cin % 16 == 0 always take v6
@@ -2385,7 +2572,7 @@ static int run_wgrad(const Mri3dConvGeom& g, const void* x, const void* dy, floa
     const int TGA = p.TG + (bias ? 1 : 0);
     const int nelem = p.CIT * p.COB * TGA * 256;
     hipLaunchKernelGGL(wgrad_mfma_reduce_kernel, dim3(cdiv(nelem, 64)), dim3(256), 0, s, part, dw, dbias, p.P, p.CIT,
-                       p.COB, p.CK, p.TG, TGA, g.ci, g.co);
+                       p.COB, p.CK, p.TG, TGA, g.ci, g.co, p.mode8);
     return check_launch("conv3d_wgrad(mfma)");
 }
 

@@ -80,7 +80,9 @@ def test_conv3x3x3_many_small_volumes(case, dtype):
 # variant of the tiled MFMA kernel (two taps share the 16-row weight operand, 9 accumulators, halves folded in the epilogue);
 # big enough for the tiled path (>= 256 tiles) and ragged in every axis; pitched slices; one case with a single chunk
 N8_CASES = [(2, 8, 8, 21, 35, 50, 0, 0, 71), (1, 16, 8, 17, 40, 65, 8, 8, 72), (2, 24, 8, 9, 33, 47, 0, 0, 73),
-            (1, 8, 16, 13, 41, 70, 0, 8, 74), (1, 8, 32, 9, 34, 49, 8, 0, 75), (40, 8, 8, 4, 8, 16, 0, 0, 76)]
+            (1, 8, 16, 13, 41, 70, 0, 8, 74), (1, 8, 32, 9, 34, 49, 8, 0, 75), (40, 8, 8, 4, 8, 16, 0, 0, 76),
+            # weight gradient with paired operand halves (v6, CI8 / CO8): 32 -> 8, pitched 8 -> 8, one-tile and W < 16 volumes
+            (1, 32, 8, 11, 19, 37, 0, 0, 77), (1, 8, 8, 7, 13, 33, 8, 8, 78), (3, 8, 8, 2, 6, 16, 0, 0, 79), (2, 16, 8, 5, 7, 9, 0, 0, 80)]
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
