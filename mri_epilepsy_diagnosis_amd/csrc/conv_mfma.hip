@@ -1706,6 +1706,11 @@ constexpr int DLS = 64;                   // bytes per (row, channel) line
 constexpr int BXS = BXR * 16 * DLS;       // 32768 B  X
 constexpr int BYS = BYR * 16 * DLS;       // 12288 B  dY
 constexpr int BYH = BYR * 16 * 8;         //  1536 B  dY W-halo: per line {dword holding dY[w0-1], dword holding dY[w0+TW]}
+// Sixteen zero bytes in device memory: what an out-of-volume 16-byte piece of a border tile loads.  Selecting the ADDRESS
+// (piece or zeros) instead of the loaded VALUE (`ok ? loaded : 0`) keeps the staging wait-free: a select on loaded data makes
+// hipcc wait for the load on the spot, i.e. the full memory latency in front of the tile's MFMAs.
+__device__ const float g_zero16[4] = {0.f, 0.f, 0.f, 0.f};
+
 __device__ __forceinline__ int rot_slot(int q, int c) { return (q + 2 * ((c >> 3) & 1)) & 3; }
 
 // eight voxels x eight channels (v[j] = the 16-byte channel vector of voxel j) -> out[c] = the 8 voxels of channel c
@@ -1815,8 +1820,8 @@ conv_mfma_wgrad_bf16_kernel(const bf16_t* __restrict__ x, const bf16_t* __restri
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 const int gw = w0 + 8 * s_wg + j;
-                const uint4 t = ldg4u(src + (int64_t)min(gw, W - 1) * x_ld);   // unconditional, explicitly global (see wgrad6)
-                vx[j] = (rok && gw < W) ? t : zero4;
+                // unconditional, explicitly global; an out-of-volume piece reads g_zero16 (address select: no wait on the load here)
+                vx[j] = ldg4u((rok && gw < W) ? src + (int64_t)gw * x_ld : reinterpret_cast<const bf16_t*>(g_zero16));
             }
         }
         if (is_y) {   // ---- dY: 12 rows x 4 w-groups x 2 channel halves
@@ -1827,16 +1832,14 @@ conv_mfma_wgrad_bf16_kernel(const bf16_t* __restrict__ x, const bf16_t* __restri
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 const int gw = w0 + 8 * s_wg + j;
-                const uint4 t = ldg4u(src + (int64_t)min(gw, W - 1) * y_ld);
-                vy[j] = (rok && gw < W) ? t : zero4;
+                vy[j] = ldg4u((rok && gw < W) ? src + (int64_t)gw * y_ld : reinterpret_cast<const bf16_t*>(g_zero16));
             }
         }
         if (is_h) {   // ---- dY W-halo voxels w0 - 1 and w0 + 32
             const int gd = d0 + hy_row / BTH, gh = h0 + hy_row % BTH, gw = h_side ? w0 + BTW : w0 - 1;
             const int c0 = cob * 16 + 8 * h_half;
             const bool ok = gd < D && gh < H && (unsigned)gw < (unsigned)W && c0 < Co;
-            const uint4 ht = ldg4u(dy + ((((int64_t)n * D + (ok ? gd : 0)) * H + (ok ? gh : 0)) * W + (ok ? gw : 0)) * y_ld + (c0 < Co ? c0 : 0));
-            vh = ok ? ht : zero4;
+            vh = ldg4u(ok ? dy + ((((int64_t)n * D + gd) * H + gh) * W + gw) * y_ld + c0 : reinterpret_cast<const bf16_t*>(g_zero16));
         }
     };
     auto store_tile = [&]() {
@@ -2074,6 +2077,8 @@ conv_mfma_wgrad6_kernel(const float* __restrict__ x, const float* __restrict__ d
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const bool ok = rok && w0 + 4 * s_wg + j < W;
+                // (the address-select form of the bf16 kernel — out-of-volume pieces read g_zero16, no wait here — costs this kernel
+                // two more registers than it has: 2 spills, 48 -> 16 layer 3.33 -> 3.47 ms)
                 const float4 t = ldg4(xb + (ok ? xrel[u] + (unsigned)(j * x_ld) : xsafe));
                 vx[u][j] = ok ? t : zero4;
             }
