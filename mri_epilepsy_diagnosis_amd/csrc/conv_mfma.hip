@@ -243,7 +243,9 @@ conv_mfma_fwd2_kernel(const T* __restrict__ x, const float* __restrict__ wp, con
     constexpr int BUF = kStg * 256 * 4;  // floats per LDS buffer: the halo tile rounded up to kStg 16-byte pieces per lane
     extern __shared__ __attribute__((aligned(16))) float lds[];
 
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform BY CONSTRUCTION: told to hipcc, so that everything
+                                                               // derived from it (output plane, tile base pointers) stays scalar
     const int li = lane & 15, kq = lane >> 4;
     const int nchunks = (Kc + CK - 1) / CK;   // bf16 with Kc % 16 == 8: the last chunk's upper piece is zero-filled
     // Tile -> workgroup map (speed only): blocks b and b+8 share an XCD (round-robin dispatch), so XCD k = b & 7 owns the
@@ -636,47 +638,58 @@ conv_mfma_fwd2_kernel(const T* __restrict__ x, const float* __restrict__ wp, con
         MRI3D_STAMP(t_mfma);
         MRI3D_STAMP_ADD(0, t_item, t_mfma);
         if (cur.ch == nchunks - 1) {
-            // epilogue: lane holds channels 4*kq..4*kq+3 of voxel li of every 16x16 tile
+            // epilogue: lane holds channels 4*kq..4*kq+3 of voxel li of every 16x16 tile.  Everything that does not depend on the
+            // lane is kept scalar — the output plane (wv is wave-uniform), which tensor an N-tile goes to, the tile's base pointer, the
+            // row-in-volume tests — and the lane's own test (its channels and its voxel column exist) is made ONCE around the eight
+            // rows: a one-chunk tile (every item of the 16-channel bf16 layers) pays this block per item.
             const int od = cur.d0 + wv;
             if (od < D) {
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) {
-                    const int co = (cur.nt0 + nt) * 16 + 4 * kq;
-                    if (co < Nc) {
-                        const bool second = y2 != nullptr && co >= nsplit;   // uniform per N-tile (nsplit % 16 == 0)
-                        T* const yd = second ? y2 : y;
-                        const int yld = second ? y2_ld : y_ld, cd = second ? co - nsplit : co;
-                        const bool vec = (co + 3 < Nc) && ((yld & 3) == 0);
-                        float4 bv = bias0[nt];   // one N-tile and one N-block: loaded once per kernel
-                        if (bias && (NT > 1 || gy > 1)) {
-                            bv = make_float4(0.f, 0.f, 0.f, 0.f);
-                            bv.x = bias[co];
-                            if (co + 1 < Nc) bv.y = bias[co + 1];
-                            if (co + 2 < Nc) bv.z = bias[co + 2];
-                            if (co + 3 < Nc) bv.w = bias[co + 3];
-                            // consume the loads HERE on every path: a bias register still "pending" at the loop's back edge
-                            // (no row of this lane in the volume) makes hipcc wait vmcnt(0) at its next reuse — at the top
-                            // of the next item, right behind the freshly issued DMA pieces
-                            asm volatile("" ::"v"(bv.x), "v"(bv.y), "v"(bv.z), "v"(bv.w));
-                        }
-                        const int ow = cur.w0 + li;
-                        // scalar 64-bit tile base + 32-bit lane / row offsets: the epilogue of a one-chunk tile (every item of the
-                        // 16-channel bf16 layers) otherwise pays three 64-bit vector multiply-adds per output row
-                        T* const ytile = yd + ((((int64_t)cur.n * D + od) * H + cur.h0) * W + cur.w0) * yld;
-                        const unsigned lane_off = (unsigned)(li * yld + cd), row_step = (unsigned)(W * yld);
+                    const int cob = (cur.nt0 + nt) * 16;   // wave-uniform
+                    if (cob >= Nc) continue;
+                    const bool second = y2 != nullptr && cob >= nsplit;   // nsplit % 16 == 0: an N-tile lives in one tensor
+                    T* const yd = second ? y2 : y;
+                    const int yld = second ? y2_ld : y_ld, cbase = second ? cob - nsplit : cob;
+                    const int co = cob + 4 * kq;
+                    const bool vec = (co + 3 < Nc) && ((yld & 3) == 0);
+                    float4 bv = bias0[nt];   // one N-tile and one N-block: loaded once per kernel
+                    if (bias && (NT > 1 || gy > 1) && co < Nc) {
+                        bv = make_float4(0.f, 0.f, 0.f, 0.f);
+                        bv.x = bias[co];
+                        if (co + 1 < Nc) bv.y = bias[co + 1];
+                        if (co + 2 < Nc) bv.z = bias[co + 2];
+                        if (co + 3 < Nc) bv.w = bias[co + 3];
+                    }
+                    // consume the loads HERE on every path: a bias register still "pending" at the loop's back edge makes hipcc
+                    // wait vmcnt(0) at its next reuse — at the top of the next item, right behind the freshly issued DMA pieces
+                    if (bias && (NT > 1 || gy > 1)) asm volatile("" ::"v"(bv.x), "v"(bv.y), "v"(bv.z), "v"(bv.w));
+                    // scalar 64-bit tile base + 32-bit lane / row offsets
+                    T* const ytile = yd + (((((int64_t)cur.n * D + od) * H + cur.h0) * W + cur.w0) * yld + cbase);
+                    const unsigned lane_off = (unsigned)(li * yld + 4 * kq), row_step = (unsigned)(W * yld);
+                    if (co < Nc && cur.w0 + li < W) {
+                        if ((Nc & 3) == 0 && (yld & 3) == 0) {   // wave-uniform: one vector store per row, nothing else
 #pragma unroll
-                        for (int m = 0; m < TH; ++m) {
-                            const int oh = cur.h0 + m;
-                            if (oh < H && ow < W) {
-                                T* yp = ytile + (lane_off + (unsigned)m * row_step);
-                                const f32x4 a = acc[m][nt];
-                                if (vec) {
-                                    stf4(yp, make_float4(a[0] + bv.x, a[1] + bv.y, a[2] + bv.z, a[3] + bv.w));
-                                } else {
-                                    stf(yp, a[0] + bv.x);
-                                    if (co + 1 < Nc) stf(yp + 1, a[1] + bv.y);
-                                    if (co + 2 < Nc) stf(yp + 2, a[2] + bv.z);
-                                    if (co + 3 < Nc) stf(yp + 3, a[3] + bv.w);
+                            for (int m = 0; m < TH; ++m) {
+                                if (cur.h0 + m < H) {   // wave-uniform
+                                    const f32x4 a = acc[m][nt];
+                                    stf4(ytile + (lane_off + (unsigned)m * row_step), make_float4(a[0] + bv.x, a[1] + bv.y, a[2] + bv.z, a[3] + bv.w));
+                                }
+                            }
+                        } else {
+#pragma unroll
+                            for (int m = 0; m < TH; ++m) {
+                                if (cur.h0 + m < H) {
+                                    T* yp = ytile + (lane_off + (unsigned)m * row_step);
+                                    const f32x4 a = acc[m][nt];
+                                    if (vec) {
+                                        stf4(yp, make_float4(a[0] + bv.x, a[1] + bv.y, a[2] + bv.z, a[3] + bv.w));
+                                    } else {
+                                        stf(yp, a[0] + bv.x);
+                                        if (co + 1 < Nc) stf(yp + 1, a[1] + bv.y);
+                                        if (co + 2 < Nc) stf(yp + 2, a[2] + bv.z);
+                                        if (co + 3 < Nc) stf(yp + 3, a[3] + bv.w);
+                                    }
                                 }
                             }
                         }
