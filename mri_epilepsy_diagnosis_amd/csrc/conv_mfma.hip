@@ -2392,13 +2392,19 @@ static bool mfma_wgrad_plan(const Mri3dConvGeom& g, MfmaWgradPlan& p) {
     p.v2 = (g.ci % 8 == 0 && g.co % 4 == 0 && g.y_ld % 4 == 0) ? (g.ci % 16 == 0 ? 2 : 1) : 0;
     if (g.dtype == MRI3D_BF16 && g.ci % 8 == 0 && g.co % 8 == 0 && g.x_ld % 8 == 0 && g.y_ld % 8 == 0) p.v2 = 3;
     if (p.v2 == 2 && g.dtype == MRI3D_F32) p.v2 = 4;
-    // v6 with eight-channel operands: 16k -> 8 (dY columns paired over kw) and 8 -> 8 (X rows paired over (kd, kh) as well);
-    // 8 -> 16 stays on v3 (same MFMA count either way)
+    // v6 with eight-channel operands: 16k -> 8 (dY columns paired over kw) and 8 -> 8 (X rows paired over (kd, kh) as well)
     p.mode8 = 0;
     if (g.dtype == MRI3D_F32 && g.co == 8 && g.y_ld % 4 == 0 && g.x_ld % 4 == 0 && (g.ci % 16 == 0 || g.ci == 8)) {
         p.v2 = 4;
         p.mode8 = 2 | (g.ci == 8 ? 1 : 0);
     }
+#if defined(MRI3D_EXPERIMENT_WG6_CI8)   // tuning builds: 8 -> 16k through v6 with paired X rows only (15 MFMAs per k-step against v3's
+    // 14, but v6's staging and fragment reads): 0.80 -> 0.77 ms on the U-Net's 8 -> 16 layer, 0.03 ms of a 31 ms step — not shipped
+    if (g.dtype == MRI3D_F32 && g.ci == 8 && g.co % 16 == 0 && g.y_ld % 4 == 0 && g.x_ld % 4 == 0) {
+        p.v2 = 4;
+        p.mode8 = 1;
+    }
+#endif
     if (p.v2 == 3) p.CK = 16;
     else if (p.mode8) p.CK = 16;
     else if (p.v2 != 0 && g.ci % 16 == 0) p.CK = 16;
@@ -2518,7 +2524,7 @@ static void run_mfma_wgrad(const MfmaWgradPlan& p, const Mri3dConvGeom& g, const
         if constexpr (sizeof(T) == 4) {
             dim3 grid(p.P, p.CIT, p.COB);
 #define MRI3D_WG6(Bv)                                                                                                 \
-    if (p.mode8 == 3) MRI3D_WG6M(Bv, true, true) else if (p.mode8 == 2) MRI3D_WG6M(Bv, false, true) else MRI3D_WG6M(Bv, false, false)
+    if (p.mode8 == 3) MRI3D_WG6M(Bv, true, true) else if (p.mode8 == 2) MRI3D_WG6M(Bv, false, true) else if (p.mode8 == 1) MRI3D_WG6M(Bv, true, false) else MRI3D_WG6M(Bv, false, false)
 #define MRI3D_WG6M(Bv, I8, O8)                                                                                        \
     {                                                                                                                 \
         auto kern = conv_mfma_wgrad6_kernel<Bv, I8, O8>;                                                              \
