@@ -23,6 +23,30 @@ def pytest_collection_modifyitems(config, items):
             item.add_marker(skip)
 
 
+_exit_status = [None]
+
+
+def pytest_sessionfinish(session, exitstatus):
+    _exit_status[0] = int(exitstatus)
+
+
+@pytest.hookimpl(trylast=True)
+def pytest_unconfigure(config):
+    """Leave a GPU session through os._exit once pytest has reported.  One run on the GPU box ended with SIGABRT (rc 134) at about
+    the time its last test finishes (its output was lost; the same tests passed in every other run, before and after) — consistent
+    with an abort in interpreter teardown (torch / HIP runtime finalisers), which this removes.  The session's exit status is final
+    here, so nothing is hidden: a failing or crashing TEST still fails the run.  CPU sessions exit normally."""
+    if _exit_status[0] is None or "torch" not in sys.modules:
+        return
+    import torch
+    if not (torch.cuda.is_available() and torch.cuda.is_initialized()):
+        return
+    torch.cuda.synchronize()
+    sys.stdout.flush()
+    sys.stderr.flush()
+    os._exit(_exit_status[0])
+
+
 @pytest.fixture(scope="session")
 def golden_dir():
     return GOLDEN
