@@ -157,7 +157,11 @@ extern "C" void mri3d_debug_block_spans(unsigned long long* out) {
     (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_block_span), sizeof(unsigned long long) * 2 * 1024);
 }
 // the phase sums stay in (scalar) registers until the kernel's end: a stamp must not add memory operations or waits to the loop
-#define MRI3D_STAMP(var) unsigned long long var = __builtin_readcyclecounter()
+// (a stamp is pinned by scheduling barriers: s_memtime depends on nothing, and hipcc otherwise moves it across the MFMAs it brackets)
+#define MRI3D_STAMP(var)                     \
+    __builtin_amdgcn_sched_barrier(0);       \
+    unsigned long long var = __builtin_readcyclecounter(); \
+    __builtin_amdgcn_sched_barrier(0)
 #define MRI3D_STAMP_ADD(slot, a, b) (stamp_acc[slot] += (b) - (a))
 #else
 #define MRI3D_STAMP(var)
@@ -673,7 +677,11 @@ conv_mfma_fwd2_kernel(const T* __restrict__ x, const float* __restrict__ wp, con
                             for (int m = 0; m < TH; ++m) {
                                 if (cur.h0 + m < H) {   // wave-uniform
                                     const f32x4 a = acc[m][nt];
+#if defined(MRI3D_EXPERIMENT_NO_STORE)   // tuning builds: the sums are formed, nothing is written
+                                    asm volatile("" ::"v"(a[0] + bv.x), "v"(a[1] + bv.y), "v"(a[2] + bv.z), "v"(a[3] + bv.w));
+#else
                                     stf4(ytile + (lane_off + (unsigned)m * row_step), make_float4(a[0] + bv.x, a[1] + bv.y, a[2] + bv.z, a[3] + bv.w));
+#endif
                                 }
                             }
                         } else {
