@@ -975,6 +975,7 @@ conv_mfma_direct_kernel(const T* __restrict__ in, const float* __restrict__ wp, 
 struct MfmaFwdPlan {
     int CK, NT, NTT, gy, nchunks, tilesD, tilesH, tilesW, ntiles, grid;
     int small;   // served by the LDS-free kernel (conv_mfma_direct_kernel) when there are fewer tiles than workgroup slots
+    int narrow;  // ... or when the volume is narrower than a tile row (then also with BatchNorm statistics requested)
     size_t wp_floats, s_wp_floats, smem, stat_smem;   // packed-weight image of the tiled / the small-volume kernel
 };
 
@@ -1082,6 +1083,16 @@ static bool mfma_fwd_plan(const Mri3dConvGeom& g, bool dgrad, MfmaFwdPlan& p) {
         p.small = 1;
         p.s_wp_floats = dp.wp_floats;
     }
+    // Volumes at most half a tile row wide (the 8^3 level of the patch CNN, cnn_model.py:104-175, batch 512): a 16-voxel tile row
+    // would be half padding.  The LDS-free kernel's M-tiles are 16 consecutive voxels of the flattened index space (two rows of
+    // eight), nothing is wasted: 64 -> 64 @ 8^3 x 512 forward 61 -> 90, data gradient 65 -> 97 TFLOP/s.  (No fused BatchNorm
+    // statistics there: conv_mfma_fwd_stat_blocks() answers 0 and the statistics pass reads the small output once.)
+    p.narrow = 0;
+    if (!bf && g.wi <= 8 && direct_plan(g, dgrad, dp)) {
+        p.small = 1;
+        p.narrow = 1;
+        p.s_wp_floats = dp.wp_floats;
+    }
     return true;
 }
 
@@ -1172,7 +1183,7 @@ int conv_mfma_fwd(const Mri3dConvGeom& g, const void* x, const float* w, const f
 // number of per-workgroup statistics partials the forward kernel writes for this geometry (0: not served by the MFMA path)
 int conv_mfma_fwd_stat_blocks(const Mri3dConvGeom& g) {
     MfmaFwdPlan p;
-    if (!mfma_fwd_plan(g, false, p) || p.NTT > 8) return 0;   // LDS statistics slots for up to 128 output channels
+    if (!mfma_fwd_plan(g, false, p) || p.NTT > 8 || p.narrow) return 0;   // LDS statistics slots for up to 128 output channels
     return p.grid;
 }
 

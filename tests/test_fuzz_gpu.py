@@ -67,7 +67,10 @@ def test_conv3x3x3_small_volumes(case):
 # borders in every dimension, 1 / 2 / 3 chunks (fp32 16 channels, bf16 32 channels per chunk; bf16 48 = a half-empty second chunk),
 # three N-blocks (the 48-channel data gradient), pitched inputs and outputs
 LARGE_BATCH_CASES = [(64, 16, 16, 9, 13, 21, 0, 0, 41), (72, 48, 16, 5, 9, 19, 0, 8, 42), (96, 16, 48, 3, 10, 17, 16, 0, 43),
-            (40, 32, 16, 11, 9, 33, 8, 8, 44), (260, 16, 16, 2, 3, 5, 0, 0, 45)]
+            (40, 32, 16, 11, 9, 33, 8, 8, 44), (260, 16, 16, 2, 3, 5, 0, 0, 45),
+            # volumes at most 8 voxels wide go to the LDS-free MFMA kernel whatever the batch (two rows per 16-voxel M-tile; an M-tile
+            # may straddle rows, planes and samples): the patch CNN's 8^3 level, a ragged one, pitched, > 32 MB of input
+            (128, 32, 64, 8, 8, 8, 0, 0, 46), (70, 16, 24, 5, 7, 6, 8, 0, 47), (300, 64, 64, 8, 8, 8, 0, 0, 48)]
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
