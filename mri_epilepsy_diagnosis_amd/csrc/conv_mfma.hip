@@ -974,7 +974,8 @@ conv_mfma_direct_kernel(const T* __restrict__ in, const float* __restrict__ wp, 
 // ------------------------------------------------------------------ host side
 struct MfmaFwdPlan {
     int CK, NT, NTT, gy, nchunks, tilesD, tilesH, tilesW, ntiles, grid;
-    int small;   // served by the LDS-free kernel (conv_mfma_direct_kernel) when there are fewer tiles than workgroup slots
+    int small;   // served by the LDS-free kernel (conv_mfma_direct_kernel): 1 = fewer than 256 work units (or narrow / strided), 2 = fewer
+                 // than one per workgroup slot (a preference: split operands and fused statistics stay on the tiled kernel)
     int narrow;  // ... or when the volume is narrower than a tile row (then also with BatchNorm statistics requested)
     size_t wp_floats, s_wp_floats, smem, stat_smem;   // packed-weight image of the tiled / the small-volume kernel
 };
@@ -1073,14 +1074,17 @@ static bool mfma_fwd_plan(const Mri3dConvGeom& g, bool dgrad, MfmaFwdPlan& p) {
     int64_t st = (int64_t)p.ntiles * p.gy;  // (spatial tile, n-tile block) work units
     if (st > 0x7fffffff) return false;
     p.grid = (int)std::min<int64_t>(st, 512);  // 2 resident workgroups per CU x 256 CUs
-    // Small volumes (fp32): fewer work units than workgroup slots — the wave-per-M-tile kernel fills the chip instead.  Its
-    // operands come from L2 / the Infinity Cache, so it is only used while the input is small (<= 32 MB) and the tiled grid would be under half full.
+    // Small volumes (fp32): no more work units than workgroup slots — the wave-per-M-tile kernel fills the chip instead.  Its
+    // operands come from L2 / the Infinity Cache, so it is only used while the input is small (<= 32 MB).
     p.small = 0;
     p.s_wp_floats = 0;
     const int64_t nvox = (int64_t)g.n * g.di * g.hi * g.wi;
     DirectPlan dp;
-    if (!bf && st < 256 && nvox * Kc * 4 <= ((int64_t)32 << 20) && direct_plan(g, dgrad, dp)) {   // bf16 tensors stay on the bf16 MFMA
-        p.small = 1;
+#ifndef MRI3D_SMALL_UNITS
+#define MRI3D_SMALL_UNITS 512   // one work unit per workgroup slot or fewer.  Measured (tools/small_units_ab.sh): 256 -> 512 moves 32 -> 32
+#endif                          // @ 40x48x40 x 2 from 64 to 72 and 64 -> 64 @ 40x48x40 from 68 to 80 TFLOP/s; 1024 loses on 32 -> 64 (85 -> 79)
+    if (!bf && st < MRI3D_SMALL_UNITS && nvox * Kc * 4 <= ((int64_t)32 << 20) && direct_plan(g, dgrad, dp)) {   // bf16 tensors stay on the bf16 MFMA
+        p.small = st < 256 ? 1 : 2;   // 2: a preference only — split operands and fused statistics still take the tiled kernel
         p.s_wp_floats = dp.wp_floats;
     }
     // Volumes at most half a tile row wide (the 8^3 level of the patch CNN, cnn_model.py:104-175, batch 512): a 16-voxel tile row
@@ -1122,8 +1126,8 @@ static int run_mfma_fwd(const Mri3dConvGeom& g, bool dgrad, const void* in_v, co
     const int Kc = dgrad ? g.co : g.ci, Nc = dgrad ? g.ci : g.co;
     const int in_ld = dgrad ? g.y_ld : g.x_ld, out_ld = dgrad ? g.x_ld : g.y_ld;
     int total = (int)p.wp_floats;
-    MRI3D_REQUIRE(sp.second == nullptr || (!p.small && !strided), MRI3D_ENOTSUP, "conv3d(mfma): split operands need the tiled kernel");
-    if (p.small && stat_part == nullptr) {
+    MRI3D_REQUIRE(sp.second == nullptr || (p.small != 1 && !strided), MRI3D_ENOTSUP, "conv3d(mfma): split operands need the tiled kernel");
+    if (p.small && stat_part == nullptr && sp.second == nullptr) {
         if (!strided) MRI3D_REQUIRE(direct_plan(g, dgrad, dp), MRI3D_ENOTSUP, "conv3d(mfma): unsupported geometry");
         const int stotal = (int)dp.wp_floats;
         hipLaunchKernelGGL(pack_w_mfma_kernel, dim3(std::min(cdiv(stotal, 256), 2048)), dim3(256), 0, s, w, wp, g.co, g.ci,
@@ -2472,8 +2476,8 @@ bool conv_mfma_cat_supported(const Mri3dConvGeom& g, int split, int second_ld, i
     if (direct_only(g)) return false;
     MfmaFwdPlan p;
     MfmaWgradPlan q;
-    if (pass == MRI3D_PASS_FWD) return mfma_fwd_plan(g, false, p) && !p.small && (g.ci - split) % 8 == 0;
-    if (pass == MRI3D_PASS_DGRAD) return mfma_fwd_plan(g, true, p) && !p.small && (g.ci - split) % 4 == 0;   // N side: 16-channel tiles
+    if (pass == MRI3D_PASS_FWD) return mfma_fwd_plan(g, false, p) && p.small != 1 && (g.ci - split) % 8 == 0;
+    if (pass == MRI3D_PASS_DGRAD) return mfma_fwd_plan(g, true, p) && p.small != 1 && (g.ci - split) % 4 == 0;   // N side: 16-channel tiles
     if (pass == MRI3D_PASS_WGRAD) return mfma_wgrad_plan(g, q) && (q.v2 == 4 ? (g.ci - split) % 16 == 0 : q.v2 == 3);
     return false;
 }

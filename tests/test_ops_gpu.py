@@ -568,10 +568,35 @@ def test_max_pool3d_2_nan_and_index_semantics_equal_torch(dtype):
 
 # (batch, Ca, Cb, Cout, volume, channel padding of the second tensor's buffer, bias, served by the split kernels in fp32 / bf16)
 CAT_CASES = [(2, 16, 32, 16, (24, 40, 70), 0, True, True, True), (2, 32, 64, 32, (21, 33, 70), 8, True, True, True),
-             (3, 16, 16, 8, (17, 40, 65), 0, False, True, True),
+             (5, 16, 16, 8, (17, 40, 65), 0, False, True, True),       # (>= 512 work units in every pass: below that the plain convolution
+                                                                       #  prefers the LDS-free kernel and the sums are ordered differently)
              (2, 16, 24, 16, (24, 40, 70), 0, True, False, True),      # 24 trailing channels: not a ci-tile multiple for the fp32 weight gradient
              (1, 8, 16, 16, (24, 40, 70), 0, True, False, False),      # 8 leading channels: the split must be a multiple of 16
              (1, 16, 32, 16, (6, 7, 9), 0, True, False, True)]         # tiny volume: fp32 runs on the LDS-free kernel (no split support)
+
+
+def test_conv3d_cat_between_256_and_512_work_units_stays_on_the_tiled_kernel():
+    """256 <= work units < 512 (fp32): the plain convolution prefers the LDS-free MFMA kernel, the split-operand one keeps the
+    tiled kernel — different summation orders, so the two agree to rounding, not bit for bit; the split path must still be served."""
+    g = torch.Generator().manual_seed(5)
+    sp = (17, 40, 65)
+    xa = torch.randn(3, 16, *sp, generator=g).cuda().contiguous(memory_format=torch.channels_last_3d)
+    xb = torch.randn(3, 16, *sp, generator=g).cuda().contiguous(memory_format=torch.channels_last_3d)
+    wt = (torch.randn(8, 32, 3, 3, 3, generator=g) / np.sqrt(27 * 32)).cuda()
+    dy = torch.randn(3, 8, *sp, generator=g).cuda().contiguous(memory_format=torch.channels_last_3d)
+    res = []
+    for split in (True, False):
+        a, b, w = xa.clone().requires_grad_(True), xb.clone().requires_grad_(True), wt.clone().requires_grad_(True)
+        if split:
+            y = ops.conv3d_cat(a, b, w, None, padding=1)
+            assert "Conv3dCatFn" in type(y.grad_fn).__name__
+        else:
+            y = ops.conv3d(torch.cat((a, b), dim=1).contiguous(memory_format=torch.channels_last_3d), w, None, padding=1)
+        y.backward(dy)
+        res.append((y.detach(), a.grad, b.grad, w.grad))
+    for name, p, q in zip(("y", "dxa", "dxb", "dw"), res[0], res[1]):
+        scale = q.abs().max().item()
+        assert (p - q).abs().max().item() <= 2e-5 * scale, (name, (p - q).abs().max().item(), scale)
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
