@@ -6,7 +6,10 @@ import sys
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from mri_epilepsy_diagnosis_amd import ops  # noqa: E402
+from mri_epilepsy_diagnosis_amd import _lib, ops  # noqa: E402
+
+if os.environ.get("MRI3D_BENCH_LIB"):   # a tuning build (python -m mri_epilepsy_diagnosis_amd.build --variant NAME -D...), tools only
+    _lib.LIB_PATH = os.path.abspath(os.environ["MRI3D_BENCH_LIB"])
 
 a = sys.argv[1:]
 ci, co, kd, kh, kw, sd, sh, sw, pd, ph, pw, d, h, w = (int(v) for v in a[:14])
