@@ -206,8 +206,9 @@ class KernelTimer:
     """Optional per-operator device timing: when installed (bench.py), every C-ABI call made through `_timed` is
     bracketed by two events recorded on the stream the kernels are enqueued on (torch's current stream)."""
 
-    def __init__(self):
+    def __init__(self, only=None):
         self.records = []  # (tag, work, start_event, end_event)
+        self.only = None if only is None else frozenset(only)   # bracket these operator tags only (None: every operator)
 
     def summary(self):
         torch.cuda.synchronize()
@@ -256,16 +257,18 @@ class _timed:
 
     def __enter__(self):
         if _timer is None and _roctx is None:
+            self.e0 = None
             return
         self.tag = self.tag_fn()
         if _roctx is not None:
             _roctx.roctxRangePushA(self.tag.encode())
-        if _timer is not None:
+        self.e0 = None
+        if _timer is not None and (_timer.only is None or self.tag in _timer.only):
             self.e0 = torch.cuda.Event(enable_timing=True)
             self.e0.record()
 
     def __exit__(self, *exc):
-        if _timer is not None:
+        if _timer is not None and self.e0 is not None:
             e1 = torch.cuda.Event(enable_timing=True)
             e1.record()
             _timer.records.append((self.tag, self.work_fn() if self.work_fn is not None else None, self.e0, e1))
