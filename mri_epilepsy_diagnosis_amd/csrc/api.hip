@@ -46,6 +46,7 @@ int conv_mfma_fwd_stats(const Mri3dConvGeom& g, const void* x, const float* w, c
 // conv_pointwise.hip
 bool conv_pointwise_supported(const Mri3dConvGeom& g, int pass);
 size_t conv_pointwise_workspace_bytes(const Mri3dConvGeom& g, int pass);
+int conv_pointwise_fwd(const Mri3dConvGeom& g, const void* x, const float* w, const float* bias, void* y, hipStream_t s);
 int conv_pointwise_dgrad(const Mri3dConvGeom& g, const void* dy, const float* w, const float* bias, void* dx,
                          hipStream_t s);
 int conv_pointwise_wgrad(const Mri3dConvGeom& g, const void* x, const void* dy, float* dw, float* dbias, void* ws,
@@ -100,6 +101,8 @@ extern "C" int mri3d_conv3d_fwd(const Mri3dConvGeom* g, const void* x, const voi
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (conv_mfma_supported(*g, MRI3D_PASS_FWD) && aligned16(x, y, workspace))
         return conv_mfma_fwd(*g, x, (const float*)w, (const float*)bias, y, workspace, ws_bytes, s);
+    if (conv_pointwise_supported(*g, MRI3D_PASS_FWD) && aligned_vec4(g->dtype, x))
+        return conv_pointwise_fwd(*g, x, (const float*)w, (const float*)bias, y, s);
     return conv_generic_fwd(*g, x, (const float*)w, (const float*)bias, y, workspace, ws_bytes, s);
 }
 

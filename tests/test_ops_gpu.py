@@ -34,6 +34,9 @@ CONV_CASES = [
     ("pw_64_8", 2, 64, 8, (6, 7, 8), 1, 1, 0, 1, True),
     ("pw_16_5", 1, 16, 5, (6, 7, 8), 1, 1, 0, 1, True),
     ("pw_128_64", 1, 128, 64, (4, 5, 6), 1, 1, 0, 1, False),
+    ("pw_8_3", 2, 8, 3, (5, 9, 13), 1, 1, 0, 1, True),       # forward on the lanes-per-voxel kernel: 2 / 1 / 16 lanes per voxel,
+    ("pw_4_1", 1, 4, 1, (7, 6, 5), 1, 1, 0, 1, False),       # 1-4 output channels, voxel counts that are no multiple of anything
+    ("pw_64_4", 1, 64, 4, (3, 7, 11), 1, 1, 0, 1, True),
     ("mfma_24_40", 1, 24, 40, (6, 9, 17), 3, 1, 1, 1, True),
     ("mfma_64_128_ragged", 1, 64, 128, (3, 5, 7), 3, 1, 1, 1, False),
     ("ragged_3x3x3", 1, 16, 16, (5, 7, 9), 3, 1, 1, 1, False),
