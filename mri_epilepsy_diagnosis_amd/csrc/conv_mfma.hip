@@ -20,6 +20,7 @@
 // MFMA peak; algorithmic FLOPs = 2 * N*D*H*W * Cin * Cout * 27 per pass.
 #include "common.h"
 #include <stdlib.h>
+#include <type_traits>
 
 namespace mri3d {
 
@@ -1961,6 +1962,206 @@ conv_mfma_wgrad_bf16_kernel(const bf16_t* __restrict__ x, const bf16_t* __restri
     for (int i = tid; i < TGA * 256; i += 256) out[i] = red[i];
 }
 
+// ------------------------------------------------------------------ bf16 weight gradient, marching along d
+// The tile kernel above re-reads its input 2.7x (a 2 x 6-row tile needs 4 x 8 rows of X) and is bound by what a CU can pull
+// through its memory pipeline (45 KB per tile in ~4 500 cycles, 10 B/clk/CU; MFMA busy 29 %).  Here a workgroup
+// owns a COLUMN of the volume — 8 rows x 32 voxels — and marches through a segment of d planes with the last planes of X in an
+// LDS ring: per output plane it fetches ONE new plane of X (10 rows) and one of dY (8 rows + the W halo), 17.5 KB instead of
+// 22.5 KB per 12 rows, and the (kd) taps read the ring.  Same transposed [channel][voxel] lines, fragments, accumulators and
+// partial layout as the tile kernel; same register staging, but two planes ahead (two register sets: the loads of step t are
+// written to LDS in step t + 2), with every per-lane address and validity fixed for the whole column.
+//   step t:  write X plane t+1 -> ring slot (t+1) & 3 and dY plane t -> buffer t & 1   (loaded in step t-2)
+//            load  X plane t+3, dY plane t+2                                             (register set t & 1)
+//            multiply plane p = t-1: X planes p-1, p, p+1 from the ring, dY plane p from buffer p & 1;   one barrier
+constexpr int MTH = 8, MXR = MTH + 2;                 // output rows / X rows per plane
+constexpr int MXP = MXR * 16 * DLS;                   // 10 240 B  one X plane
+constexpr int MXS = 4 * MXP;                          // ring of four planes
+constexpr int MYP = MTH * 16 * DLS;                   //  8 192 B  one dY plane
+constexpr int MYS = 2 * MYP;
+constexpr int MHP = MTH * 16 * 8;                     //  1 024 B  W halo of one dY plane
+constexpr int MYH = 2 * MHP;
+constexpr int kMarchSeg = 40;                         // planes per task at most (4 fill steps per task); shorter for small volumes
+
+template <bool BIAS>
+__global__ void __launch_bounds__(256, 2)
+conv_mfma_wgrad_bf16m_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ dy, float* __restrict__ part, int N,
+                             int D, int H, int W, int Ci, int x_ld, int Co, int y_ld, int nseg, int tilesH, int tilesW,
+                             int ntasks, const bf16_t* __restrict__ x2, int x2_ld, int ksplit, int segl) {
+    constexpr int TG = 27, TGA = TG + (BIAS ? 1 : 0);
+    int xc0 = (int)blockIdx.y * 16, xcn = Ci;   // conv over cat((x, x2)): the ci-tile lives in ONE of the two tensors
+    if (x2 != nullptr) {
+        if (xc0 >= ksplit) { x = x2; x_ld = x2_ld; xc0 -= ksplit; xcn = Ci - ksplit; }
+        else xcn = ksplit;
+    }
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    char* xs = reinterpret_cast<char*>(lds);
+    char* ys = xs + MXS;
+    char* yh = ys + MYS;
+    const int cit = blockIdx.y, cob = blockIdx.z;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 15, kq = lane >> 4;
+
+    f32x4 acc[TGA];
+#pragma unroll
+    for (int t = 0; t < TGA; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    bf16x8_t ones;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) ones[i] = (bf16_t)1.0f;
+
+    // staging roles, one unit (8 voxels x 8 channels) per lane at most: X rows on lanes 0..79, dY rows on lanes 128..191, the
+    // dY W-halo voxels on lanes 192..223
+    const int role = tid < 80 ? 0 : (tid >= 128 && tid < 192) ? 1 : (tid >= 192 && tid < 224) ? 2 : 3;
+    const int u = role == 0 ? tid : role == 1 ? tid - 128 : tid - 192;
+    const int s_half = u & 1, s_wg = (u >> 1) & 3, s_row = u >> 3;          // roles 0, 1
+    const int h_side = (u >> 1) & 1, hy_row = u >> 2;                        // role 2
+    const bf16_t* const tens = role == 0 ? x : dy;
+    const int ld = role == 0 ? x_ld : y_ld;
+    // operand addresses of the wave's two output rows
+    const int orow0 = wv * 2;
+    const int xline0 = (orow0 * 16 + li) * DLS + 16 * rot_slot(kq, li);                 // + slot * MXP + kh * 16 * DLS
+    const int yline0 = orow0 * 16 + li;
+    const int yrow_o = yline0 * DLS + 16 * rot_slot(kq, li);                            // + buffer * MYP
+    const bool pl_halo = kq == 0, nr_halo = kq == 3;
+    const int ypl_o = pl_halo ? yline0 * 8 : yline0 * DLS + 16 * rot_slot(kq - 1, li) + 12;   // + buffer * (MHP or MYP)
+    const int ynr_o = nr_halo ? yline0 * 8 + 4 : yline0 * DLS + 16 * rot_slot(kq + 1, li);
+    const int pl_step = pl_halo ? 16 * 8 : 16 * DLS, nr_step = nr_halo ? 16 * 8 : 16 * DLS;
+
+    uint4 v[2][8];
+    const TileWalk tw = tile_walk(ntasks);
+    for (int k = 0; k < tw.count; ++k) {
+        int task = tw.first + k * tw.stride;
+        const int w0 = (task % tilesW) * BTW;
+        task /= tilesW;
+        const int h0 = (task % tilesH) * MTH;
+        task /= tilesH;
+        const int seg = task % nseg, n = task / nseg;
+        const int dA = seg * segl, dB = min(D, dA + segl);
+        // the lane's unit for this column: element offset inside a plane, valid voxels (0..8), and which planes it may touch
+        int off0 = 0, nvalid = 0;
+        if (role == 0) {
+            const int gh = h0 - 1 + s_row, c0 = xc0 + 8 * s_half;
+            if ((unsigned)gh < (unsigned)H && c0 < xcn) {
+                off0 = (gh * W + w0 + 8 * s_wg) * x_ld + c0;
+                nvalid = min(8, max(0, W - (w0 + 8 * s_wg)));
+            }
+        } else if (role == 1) {
+            const int gh = h0 + s_row, c0 = cob * 16 + 8 * s_half;
+            if (gh < H && c0 < Co) {
+                off0 = (gh * W + w0 + 8 * s_wg) * y_ld + c0;
+                nvalid = min(8, max(0, W - (w0 + 8 * s_wg)));
+            }
+        } else if (role == 2) {
+            const int gh = h0 + hy_row, gw = h_side ? w0 + BTW : w0 - 1, c0 = cob * 16 + 8 * s_half;
+            if (gh < H && (unsigned)gw < (unsigned)W && c0 < Co) {
+                off0 = (gh * W + gw) * y_ld + c0;
+                nvalid = 1;
+            }
+        }
+        const int64_t plane_el = (int64_t)H * W * ld;
+        const bf16_t* const tbase = tens + (int64_t)n * D * plane_el + off0;
+
+        auto step = [&](auto SETC, int t) {
+            constexpr int S = decltype(SETC)::value;
+            // ---- write what step t-2 loaded: X plane t+1, dY plane t (zeros where a plane or voxel does not exist)
+            if (t >= dA - 2 && t <= dB) {
+                if (role == 0) {
+                    uint4 o[8];
+                    transpose8x8_bf16(v[S], o);
+                    char* dline = xs + ((t + 1) & 3) * MXP + (s_row * 16 + 8 * s_half) * DLS + 16 * rot_slot(s_wg, 8 * s_half);
+#pragma unroll
+                    for (int c = 0; c < 8; ++c) *reinterpret_cast<uint4*>(dline + c * DLS) = o[c];
+                } else if (role == 1) {
+                    uint4 o[8];
+                    transpose8x8_bf16(v[S], o);
+                    char* yline = ys + (t & 1) * MYP + (s_row * 16 + 8 * s_half) * DLS + 16 * rot_slot(s_wg, 8 * s_half);
+#pragma unroll
+                    for (int c = 0; c < 8; ++c) *reinterpret_cast<uint4*>(yline + c * DLS) = o[c];
+                } else if (role == 2) {   // w0 - 1: high half of dword 0;  w0 + 32: low half of dword 1
+                    const unsigned* hw = reinterpret_cast<const unsigned*>(&v[S][0]);
+#pragma unroll
+                    for (int c = 0; c < 8; ++c) {
+                        const unsigned short val = (unsigned short)((c & 1) ? (hw[c >> 1] >> 16) : (hw[c >> 1] & 0xffffu));
+                        *reinterpret_cast<unsigned short*>(yh + (t & 1) * MHP + (hy_row * 16 + 8 * s_half + c) * 8 + (h_side ? 4 : 2)) = val;
+                    }
+                }
+            }
+            // ---- load X plane t+3 / dY plane t+2 (address select: a missing piece reads the zero block; nothing waits here)
+            {
+                const int pl = role == 0 ? t + 3 : t + 2;
+                const bool pok = role == 0 ? (pl >= dA - 1 && pl <= dB && (unsigned)pl < (unsigned)D) : (pl >= dA && pl < dB);
+                const bf16_t* src = tbase + (int64_t)pl * plane_el;
+#pragma unroll
+                for (int j = 0; j < 8; ++j)
+                    v[S][j] = ldg4u((pok && j < nvalid) ? src + (int64_t)j * ld : reinterpret_cast<const bf16_t*>(g_zero16));
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            // ---- multiply plane p = t - 1
+            const int p = t - 1;
+            if (p >= dA && p < dB) {
+                const char* const xb0 = xs + ((p - 1) & 3) * MXP + xline0;
+                const char* const xb1 = xs + (p & 3) * MXP + xline0;
+                const char* const xb2 = xs + ((p + 1) & 3) * MXP + xline0;
+                const char* yrow = ys + (p & 1) * MYP + yrow_o;
+                const char* ypl = (pl_halo ? yh + (p & 1) * MHP : ys + (p & 1) * MYP) + ypl_o;
+                const char* ynr = (nr_halo ? yh + (p & 1) * MHP : ys + (p & 1) * MYP) + ynr_o;
+#pragma unroll 1
+                for (int r = 0; r < 2; ++r, yrow += 16 * DLS, ypl += pl_step, ynr += nr_step) {
+                    const uint4 b1 = *reinterpret_cast<const uint4*>(yrow);            // dY[u], the lane's eight voxels
+                    const unsigned plv = *reinterpret_cast<const unsigned*>(ypl);       // high half = dY[first - 1]
+                    const unsigned nrv = *reinterpret_cast<const unsigned*>(ynr);       // low half = dY[last + 1]
+                    uint4 bm, bp;   // dY[u - 1], dY[u + 1]
+                    bm.x = __builtin_amdgcn_alignbyte(b1.x, plv, 2);
+                    bm.y = __builtin_amdgcn_alignbyte(b1.y, b1.x, 2);
+                    bm.z = __builtin_amdgcn_alignbyte(b1.z, b1.y, 2);
+                    bm.w = __builtin_amdgcn_alignbyte(b1.w, b1.z, 2);
+                    bp.x = bm.y;
+                    bp.y = bm.z;
+                    bp.z = bm.w;
+                    bp.w = __builtin_amdgcn_alignbyte(nrv, b1.w, 2);
+                    const bf16x8_t b0v = __builtin_bit_cast(bf16x8_t, bp), b1v = __builtin_bit_cast(bf16x8_t, b1),
+                                   b2v = __builtin_bit_cast(bf16x8_t, bm);
+                    if constexpr (BIAS) acc[TG] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, b1v, acc[TG], 0, 0, 0);
+                    const int rowo = r * 16 * DLS;
+#pragma unroll
+                    for (int kdh = 0; kdh < 9; ++kdh) {
+                        const char* xb = kdh < 3 ? xb0 : (kdh < 6 ? xb1 : xb2);
+                        const bf16x8_t g = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(xb + rowo + (kdh % 3) * 16 * DLS));
+                        acc[kdh * 3 + 0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(g, b0v, acc[kdh * 3 + 0], 0, 0, 0);   // X[u] dY[u+1]
+                        acc[kdh * 3 + 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(g, b1v, acc[kdh * 3 + 1], 0, 0, 0);   // X[u] dY[u]
+                        acc[kdh * 3 + 2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(g, b2v, acc[kdh * 3 + 2], 0, 0, 0);   // X[u] dY[u-1]
+                    }
+                }
+            }
+            __syncthreads();   // this step's LDS writes are visible, its reads are done
+        };
+        // steps dA-4 .. dB, two per iteration so that the register set (t & 1) is a compile-time index
+        const int t0 = (dA - 4) & ~1;
+        for (int t = t0; t <= dB; t += 2) {
+            step(std::integral_constant<int, 0>{}, t);
+            step(std::integral_constant<int, 1>{}, t + 1);
+        }
+    }
+
+    // combine the 4 waves in a fixed order through LDS, then one partial per workgroup
+    __syncthreads();
+    float* red = lds;  // [TGA][256]
+    for (int w = 0; w < 4; ++w) {
+        if (wv == w) {
+#pragma unroll
+            for (int t = 0; t < TGA; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int o = t * 256 + (4 * kq + r) * 16 + li;
+                    red[o] = (w == 0) ? acc[t][r] : red[o] + acc[t][r];
+                }
+        }
+        __syncthreads();
+    }
+    float* out = part + (((size_t)blockIdx.x * gridDim.y + cit) * gridDim.z + cob) * (TGA * 256);
+    for (int i = tid; i < TGA * 256; i += 256) out[i] = red[i];
+}
+
 // ------------------------------------------------------------------ weight gradient, version 6 (fp32, Cin % 16 == 0)
 // The transposed tile for fp32: a line holds 16 voxels, and the MFMA K order is permuted so that k-group kq of the four k-steps
 // of a row owns voxels 4kq..4kq+3 — ONE ds_read_b128 feeds four v_mfma_f32_16x16x4_f32 k-steps.  The kw = 0 / 2 taps take the
@@ -2400,7 +2601,7 @@ wgrad_mfma_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw,
 }
 
 struct MfmaWgradPlan {
-    int CK, CIT, COB, TG, P, tilesD, tilesH, tilesW, ntiles, v2, mode8;
+    int CK, CIT, COB, TG, P, tilesD, tilesH, tilesW, ntiles, v2, mode8, segl;
     size_t part_floats, smem;
 };
 
@@ -2428,7 +2629,22 @@ static bool mfma_wgrad_plan(const Mri3dConvGeom& g, MfmaWgradPlan& p) {
         p.mode8 = 1;
     }
 #endif
-    if (p.v2 == 3) p.CK = 16;
+#ifndef MRI3D_BF16_WGRAD_MARCH_MIN_D
+#define MRI3D_BF16_WGRAD_MARCH_MIN_D 8   // (tuning builds: a huge value keeps every bf16 layer on the tile kernel)
+#endif
+    // bf16, marching along d (conv_mfma_wgrad_bf16m_kernel): when the columns x segments give every workgroup at least three
+    // tasks — segments of 40 planes, or 20 for smaller volumes (each task pays 4 staging-only fill steps; with 10-plane segments
+    // the 32 -> 32 layer at 80x96x80 ran 0.132 ms against the tile kernel's 0.122)
+    p.segl = 0;
+    if (p.v2 == 3 && g.di >= MRI3D_BF16_WGRAD_MARCH_MIN_D) {
+        const int pairs5 = cdiv(g.ci, 16) * cdiv(g.co, 16);
+        const int P5 = std::max(1, 512 / std::max(1, pairs5));
+        const int64_t cols = (int64_t)g.n * cdiv(g.hi, MTH) * cdiv(g.wi, BTW);
+        for (int sl = kMarchSeg; sl >= 20 && p.segl == 0; sl /= 2)
+            if (cols * cdiv(g.di, sl) >= (int64_t)3 * P5) p.segl = sl;
+        if (p.segl) p.v2 = 5;
+    }
+    if (p.v2 == 3 || p.v2 == 5) p.CK = 16;
     else if (p.mode8) p.CK = 16;
     else if (p.v2 != 0 && g.ci % 16 == 0) p.CK = 16;
     else if (p.v2 != 0) p.CK = 8;
@@ -2445,6 +2661,11 @@ static bool mfma_wgrad_plan(const Mri3dConvGeom& g, MfmaWgradPlan& p) {
     p.tilesD = cdiv(g.di, p.v2 >= 3 ? BTD : WTD);
     p.tilesH = cdiv(g.hi, p.v2 >= 3 ? BTH : (p.v2 == 2 ? V4TH : WTH));
     p.tilesW = cdiv(g.wi, p.v2 == 3 ? BTW : (p.v2 == 4 ? FTW : WTW));
+    if (p.v2 == 5) {   // tasks = (sample, segment of d, column): tilesD holds the segments
+        p.tilesD = cdiv(g.di, p.segl);
+        p.tilesH = cdiv(g.hi, MTH);
+        p.tilesW = cdiv(g.wi, BTW);
+    }
     int64_t nt = (int64_t)g.n * p.tilesD * p.tilesH * p.tilesW;
     if (nt > 0x7fffffff) return false;
     p.ntiles = (int)nt;
@@ -2464,6 +2685,8 @@ static bool mfma_wgrad_plan(const Mri3dConvGeom& g, MfmaWgradPlan& p) {
         p.smem = std::max<size_t>(xbuf + (size_t)WVOX * 16, red) * sizeof(float);
     } else if (p.v2 == 2) {
         p.smem = std::max<size_t>((size_t)2 * V4XBUF + 2 * V4YBUF, red) * sizeof(float);
+    } else if (p.v2 == 5) {
+        p.smem = std::max<size_t>((size_t)MXS + MYS + MYH, red * sizeof(float));
     } else if (p.v2 >= 3) {
         p.smem = std::max<size_t>((size_t)BXS + BYS + BYH, red * sizeof(float));
     }
@@ -2478,7 +2701,7 @@ bool conv_mfma_cat_supported(const Mri3dConvGeom& g, int split, int second_ld, i
     MfmaWgradPlan q;
     if (pass == MRI3D_PASS_FWD) return mfma_fwd_plan(g, false, p) && p.small != 1 && (g.ci - split) % 8 == 0;
     if (pass == MRI3D_PASS_DGRAD) return mfma_fwd_plan(g, true, p) && p.small != 1 && (g.ci - split) % 4 == 0;   // N side: 16-channel tiles
-    if (pass == MRI3D_PASS_WGRAD) return mfma_wgrad_plan(g, q) && (q.v2 == 4 ? (g.ci - split) % 16 == 0 : q.v2 == 3);
+    if (pass == MRI3D_PASS_WGRAD) return mfma_wgrad_plan(g, q) && (q.v2 == 4 ? (g.ci - split) % 16 == 0 : (q.v2 == 3 || q.v2 == 5));
     return false;
 }
 
@@ -2529,7 +2752,21 @@ template <typename T>
 static void run_mfma_wgrad(const MfmaWgradPlan& p, const Mri3dConvGeom& g, const T* x, const T* dy, float* part, bool bias,
                            hipStream_t s, ConvSplit sp = ConvSplit{nullptr, 0, 0}) {
     // the kernel template reserves the bias accumulator slot in the partial layout (TGA = TG + 1) only when BIAS
-    if (p.v2 == 3) {
+    if (p.v2 == 5) {
+        if constexpr (sizeof(T) == 2) {
+            dim3 grid(p.P, p.CIT, p.COB);
+#define MRI3D_WGM(Bv)                                                                                                 \
+    {                                                                                                                 \
+        auto kern = conv_mfma_wgrad_bf16m_kernel<Bv>;                                                                 \
+        MRI3D_SET_SMEM_ONCE(kern, p.smem);                                                                            \
+        hipLaunchKernelGGL(kern, grid, dim3(256), p.smem, s, x, dy, part, g.n, g.di, g.hi, g.wi, g.ci, g.x_ld, g.co,  \
+                           g.y_ld, p.tilesD, p.tilesH, p.tilesW, p.ntiles, (const bf16_t*)sp.second, sp.second_ld,    \
+                           sp.split, p.segl);                                                                         \
+    }
+            if (bias) MRI3D_WGM(true) else MRI3D_WGM(false)
+#undef MRI3D_WGM
+        }
+    } else if (p.v2 == 3) {
         if constexpr (sizeof(T) == 2) {
             dim3 grid(p.P, p.CIT, p.COB);
 #define MRI3D_WGB(Bv)                                                                                                 \
@@ -2610,11 +2847,11 @@ static int run_wgrad(const Mri3dConvGeom& g, const void* x, const void* dy, floa
     MRI3D_REQUIRE(ws && ws_bytes >= p.part_floats * sizeof(float), MRI3D_EWORKSPACE,
                   "conv3d_wgrad(mfma): workspace %zu < %zu", ws_bytes, p.part_floats * sizeof(float));
     MRI3D_REQUIRE(aligned_vec4(g.dtype, x, dy), MRI3D_EINVAL, "conv3d_wgrad(mfma): x/dy must be aligned to 4 elements");
-    MRI3D_REQUIRE(p.v2 != 3 || ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(dy)) & 15) == 0, MRI3D_EINVAL,
+    MRI3D_REQUIRE((p.v2 != 3 && p.v2 != 5) || ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(dy)) & 15) == 0, MRI3D_EINVAL,
                   "conv3d_wgrad(bf16 mfma): x/dy must be 16-byte aligned");
     float* part = static_cast<float*>(ws);
     const bool bias = dbias != nullptr;
-    MRI3D_REQUIRE(sp.second == nullptr || p.v2 == 3 || p.v2 == 4, MRI3D_ENOTSUP, "conv3d_wgrad(mfma): split operands need the transposed-tile kernels");
+    MRI3D_REQUIRE(sp.second == nullptr || p.v2 >= 3, MRI3D_ENOTSUP, "conv3d_wgrad(mfma): split operands need the transposed-tile kernels");
     MRI3D_DISPATCH_DTYPE(g.dtype, T, { run_mfma_wgrad<T>(p, g, static_cast<const T*>(x), static_cast<const T*>(dy), part, bias, s, sp); });
     const int TGA = p.TG + (bias ? 1 : 0);
     const int nelem = p.CIT * p.COB * TGA * 256;

@@ -79,6 +79,17 @@ def test_conv3x3x3_many_small_volumes(case, dtype):
     _run_conv_case(case, dtype)
 
 
+# bf16 weight gradient marching along d (conv_mfma_wgrad_bf16m_kernel: taken when columns x segments >= 3 tasks per workgroup): a last
+# segment of 5 / 3 / 1 planes, a last row tile of one row, a last column tile of 5 voxels, an 8-channel input tile (upper half
+# empty) read from a pitched buffer, 24 output channels (half-empty second block) written from a pitched gradient
+MARCH_CASES = [(8, 64, 64, 45, 17, 37, 0, 0, 91), (24, 8, 128, 23, 9, 33, 8, 0, 92), (64, 32, 24, 41, 12, 20, 0, 8, 93)]
+
+
+@pytest.mark.parametrize("case", MARCH_CASES, ids=lambda c: "n%d_%d-%d_%dx%dx%d_p%d_%d" % c[:8])
+def test_bf16_weight_gradient_marching_along_d(case):
+    _run_conv_case(case, torch.bfloat16)
+
+
 # exactly 8 output channels in the forward (8 -> 8, 16 -> 8, 24 -> 8) or in the data gradient (8 -> 16, 8 -> 32): the row-paired
 # variant of the tiled MFMA kernel (two taps share the 16-row weight operand, 9 accumulators, halves folded in the epilogue);
 # big enough for the tiled path (>= 256 tiles) and ragged in every axis; pitched slices; one case with a single chunk

@@ -571,6 +571,7 @@ def test_max_pool3d_2_nan_and_index_semantics_equal_torch(dtype):
 
 # (batch, Ca, Cb, Cout, volume, channel padding of the second tensor's buffer, bias, served by the split kernels in fp32 / bf16)
 CAT_CASES = [(2, 16, 32, 16, (24, 40, 70), 0, True, True, True), (2, 32, 64, 32, (21, 33, 70), 8, True, True, True),
+             (8, 32, 64, 32, (45, 17, 37), 8, True, True, True),       # bf16: the weight gradient marches along d (3 segments of 20)
              (5, 16, 16, 8, (17, 40, 65), 0, False, True, True),       # (>= 512 work units in every pass: below that the plain convolution
                                                                        #  prefers the LDS-free kernel and the sums are ordered differently)
              (2, 16, 24, 16, (24, 40, 70), 0, True, False, True),      # 24 trailing channels: not a ci-tile multiple for the fp32 weight gradient
