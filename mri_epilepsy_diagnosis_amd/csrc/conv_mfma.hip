@@ -2644,6 +2644,9 @@ static bool mfma_wgrad_plan(const Mri3dConvGeom& g, MfmaWgradPlan& p) {
             if (cols * cdiv(g.di, sl) >= (int64_t)3 * P5) p.segl = sl;
         if (p.segl) p.v2 = 5;
     }
+    // (The same structure for fp32 — tools/experiments/wgrad6m_kernel.hip, parity-green — measured no gain: 16 -> 16 1.20 -> 1.25 ms,
+    // 48 -> 16 3.35 -> 3.40 ms, 96 -> 32 1.83 -> 1.81 ms, only 32^3 x 512 patches 2.21 -> 2.03 ms.  The fp32 kernel is MFMA-bound and
+    // at its register limit; fewer staged bytes buy it nothing.)
     if (p.v2 == 3 || p.v2 == 5) p.CK = 16;
     else if (p.mode8) p.CK = 16;
     else if (p.v2 != 0 && g.ci % 16 == 0) p.CK = 16;
