@@ -285,15 +285,15 @@ conv_dgrad_taps_kernel(Mri3dConvGeom g, const T* __restrict__ dy, const float* _
         const T* yn = dy + (int64_t)n * g.dout * g.ho * g.wo * g.y_ld;
         T* xn = dx + (((int64_t)nd_ * g.hi + h0) * g.wi) * g.x_ld + cit;
         for (unsigned e = threadIdx.x; e < inner; e += blockDim.x) {
-            const int iw = e % g.wi, ih = h0 + e / g.wi;
+            const int iw = e % g.wi, ih = h0 + e / g.wi;   // (incremental counters instead of this division pair: measured, no gain)
             int64_t off[NTAPS];
             unsigned okm = 0;
 #pragma unroll
             for (int t = 0; t < NTAPS; ++t) {
-                const int nd = id + g.pd - tkd[t] * g.dd, nh = ih + g.ph - tkh[t] * g.dh, nw = iw + g.pw - tkw[t] * g.dw;
-                const int od = nd / g.sd, oh = nh / g.sh, ow = nw / g.sw;
-                const bool ok = t < taps && nd >= 0 && nh >= 0 && nw >= 0 && od * g.sd == nd && oh * g.sh == nh && ow * g.sw == nw &&
-                                od < g.dout && oh < g.ho && ow < g.wo;
+                // (launched for unit strides only — launch_dgrad — so the output voxel of a tap is the shifted input voxel: no
+                // run-time integer divisions, which were most of this kernel's instructions)
+                const int od = id + g.pd - tkd[t] * g.dd, oh = ih + g.ph - tkh[t] * g.dh, ow = iw + g.pw - tkw[t] * g.dw;
+                const bool ok = t < taps && (unsigned)od < (unsigned)g.dout && (unsigned)oh < (unsigned)g.ho && (unsigned)ow < (unsigned)g.wo;
                 okm |= ok ? (1u << t) : 0u;
                 const int cd = min(max(od, 0), g.dout - 1), chh = min(max(oh, 0), g.ho - 1), cw = min(max(ow, 0), g.wo - 1);
                 off[t] = (((int64_t)cd * g.ho + chh) * g.wo + cw) * g.y_ld;
