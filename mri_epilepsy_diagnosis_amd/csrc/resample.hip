@@ -421,6 +421,51 @@ upsample_bwd_kernel(Mri3dUpGeom g, const T* __restrict__ dy, T* __restrict__ dx,
     }
 }
 
+// ------------------------------------------------------------------ nearest-neighbour backward with an integer scale
+// The decoder of the autoencoder upsamples by 4 with nn.Upsample(mode='nearest') (AE_model.py:110-120): output size = S x input
+// size exactly, so source(o) = o / S and the gradient of a coarse voxel is the plain sum of its S x S x S fine voxels.  The generic
+// kernel above evaluates three interpolation weights per tap and loads inside `if (w != 0)` (one round trip per tap: 2.9 TB/s on
+// the 8-channel layer); here a lane owns (coarse voxel, 4-channel quad) and issues the S x S loads of one fine plane together.
+template <typename T, int S>
+__global__ void __launch_bounds__(256)
+upsample_nearest_int_bwd_kernel(Mri3dUpGeom g, const T* __restrict__ dy, T* __restrict__ dx, int hch) {
+    const unsigned CV = g.c / 4;
+    const int hchunks = (g.hi + hch - 1) / hch;
+    const int slabs = g.n * g.di * hchunks;
+    for (int slab = blockIdx.x; slab < slabs; slab += gridDim.x) {
+        const int hc = slab % hchunks, nd = slab / hchunks;
+        const int n = nd / g.di, id = nd - n * g.di;
+        const int hh0 = hc * hch, hn = min(hch, g.hi - hh0);
+        const unsigned inner = (unsigned)hn * g.wi * CV;
+        const T* dn = dy + ((int64_t)n * g.dout + (int64_t)id * S) * g.ho * g.wo * g.y_ld;   // the coarse plane's first fine plane
+        const int64_t ibase = ((int64_t)nd * g.hi + hh0) * g.wi;
+        for (unsigned e = threadIdx.x; e < inner; e += blockDim.x) {
+            const unsigned cv = e % CV, pix = e / CV;
+            const int iw = pix % g.wi, ih = hh0 + pix / g.wi;
+            float acc[4] = {0.f, 0.f, 0.f, 0.f};
+            const T* dc = dn + (((int64_t)ih * S) * g.wo + (int64_t)iw * S) * g.y_ld + cv * 4;
+#pragma unroll 1
+            for (int a = 0; a < S; ++a) {
+                V<4> gv[S][S];
+#pragma unroll
+                for (int b = 0; b < S; ++b)
+#pragma unroll
+                    for (int c = 0; c < S; ++c) gv[b][c].load(dc + (((int64_t)a * g.ho + b) * g.wo + c) * g.y_ld);
+#pragma unroll
+                for (int b = 0; b < S; ++b)
+#pragma unroll
+                    for (int c = 0; c < S; ++c)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) acc[j] += gv[b][c].v[j];
+            }
+            V<4> o;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) o.v[j] = acc[j];
+            o.store(dx + (ibase + pix) * g.x_ld + cv * 4);
+        }
+    }
+}
+
 // ------------------------------------------------------------------ trilinear x2 backward, LDS-tiled
 // The decoder's nn.Upsample(scale_factor=2, mode='trilinear', align_corners=False) (unet.UNet) is the
 // only interpolating resample on the hot path, and its transposed gather reads 4x4x4 fine voxels per coarse voxel while
@@ -966,11 +1011,23 @@ extern "C" int mri3d_upsample3d_bwd(const Mri3dUpGeom* g, const void* dy, void* 
             return check_launch("upsample3d_bwd(2x)");
         }
     }
-    int* tab = static_cast<int*>(workspace);
-    hipLaunchKernelGGL(upsample_tables_kernel, dim3(3), dim3(256), 0, s, *g, tab);
     bool v4 = vec_ok(g->dtype, g->c, g->x_ld, g->y_ld, dx, dy);
     int hch, grid;
     slab_plan(g->n * g->di, g->hi, g->wi, g->c / (v4 ? 4 : 1), hch, grid);
+    // nearest neighbour with output = S x input in every axis (S = 2, 4): the plain S^3 box sum
+    const int sc = g->di > 0 ? g->dout / g->di : 0;
+    if (!no_fast && g->mode == MRI3D_UP_NEAREST && v4 && (sc == 2 || sc == 4) && g->dout == sc * g->di && g->ho == sc * g->hi &&
+        g->wo == sc * g->wi) {
+        MRI3D_DISPATCH_DTYPE(g->dtype, T, {
+            if (sc == 4)
+                hipLaunchKernelGGL((upsample_nearest_int_bwd_kernel<T, 4>), dim3(grid), dim3(256), 0, s, *g, (const T*)dy, (T*)dx, hch);
+            else
+                hipLaunchKernelGGL((upsample_nearest_int_bwd_kernel<T, 2>), dim3(grid), dim3(256), 0, s, *g, (const T*)dy, (T*)dx, hch);
+        });
+        return check_launch("upsample3d_bwd(nearest, integer scale)");
+    }
+    int* tab = static_cast<int*>(workspace);
+    hipLaunchKernelGGL(upsample_tables_kernel, dim3(3), dim3(256), 0, s, *g, tab);
     MRI3D_DISPATCH_DTYPE(g->dtype, T, {
         if (v4)
             hipLaunchKernelGGL((upsample_bwd_kernel<T, 4>), dim3(grid), dim3(256), 0, s, *g, (const T*)dy, (T*)dx, tab, hch);
