@@ -1606,7 +1606,13 @@ conv_dgrad_strided_taps_kernel(Mri3dConvGeom g, const T* __restrict__ dy, const 
             }
         }
     }
-    for (int iw = rw + (int)threadIdx.x * g.sw; iw < g.wi; iw += 64 * g.sw) {
+    // input voxel iw = rw + k * sw: its tap kw (kw = (rw + pw) mod sw, enumerated above) reaches output voxel k + (rw + pw - kw) / sw —
+    // an exact, wave-uniform quotient per tap, so the voxel loop has no integer division
+    int tq[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) tq[t] = (rw + g.pw - tkw[t]) / g.sw;
+    int k = (int)threadIdx.x;
+    for (int iw = rw + (int)threadIdx.x * g.sw; iw < g.wi; iw += 64 * g.sw, k += 64) {
         float acc[CIT];
 #pragma unroll
         for (int j = 0; j < CIT; ++j) acc[j] = (bias != nullptr && cit + j < g.ci) ? bias[cit + j] : 0.f;
@@ -1614,9 +1620,8 @@ conv_dgrad_strided_taps_kernel(Mri3dConvGeom g, const T* __restrict__ dy, const 
         unsigned okm = 0;
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
-            const int nw = iw + g.pw - tkw[t];
-            const int ow = nw / g.sw;
-            const bool ok = t < ntap && nw >= 0 && ow < g.wo;
+            const int ow = k + tq[t];
+            const bool ok = t < ntap && (unsigned)ow < (unsigned)g.wo;
             okm |= ok ? (1u << t) : 0u;
             off[t] = rowoff[t] + (int64_t)(ok ? ow : 0) * g.y_ld;
         }
