@@ -162,6 +162,24 @@ def test_pool_upsample_cat_add_bf16():
     _close(ag, _rb(ur.detach()) + x, "add")
 
 
+@pytest.mark.parametrize("scale", [2, 4])
+def test_nearest_upsampling_backward_with_an_integer_scale_bf16(scale):
+    """nn.Upsample(scale_factor=S, mode='nearest') backward on bf16 tensors (the S^3 box-sum kernel; AE_model.py:110-120 uses S = 4):
+    fp32 accumulation of the S^3 fine gradients, one rounding of the result."""
+    ops = _ops()
+    torch.manual_seed(11)
+    x = _rb(torch.randn(2, 8, 3, 5, 7))
+    xr = x.clone().requires_grad_(True)
+    yr = F.interpolate(xr, scale_factor=scale, mode="nearest")
+    dy = _rb(torch.randn_like(yr))
+    yr.backward(dy)
+    xg = _dev(x).requires_grad_(True)
+    yg = ops.upsample3d(xg, scale_factor=scale, mode="nearest")
+    torch.testing.assert_close(yg.float().cpu(), yr.detach(), rtol=0, atol=0)
+    yg.backward(_dev(dy))
+    _close(xg.grad, xr.grad, "nearest x%d backward" % scale, ulp=1.0, abs_frac=1e-3)
+
+
 def test_softmax_dice_argmax_bf16():
     ops = _ops()
     torch.manual_seed(9)
