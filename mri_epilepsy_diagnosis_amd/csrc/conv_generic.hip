@@ -1861,9 +1861,10 @@ int conv_generic_wgrad(const Mri3dConvGeom& g, const void* x, const void* dy, fl
     float* part = static_cast<float*>(ws);
     float* bias_part = dbias ? part + p.part_floats : nullptr;
     MRI3D_DISPATCH_DTYPE(g.dtype, T, {
-        if (p.smem > 64 * 1024)
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_generic_kernel<T>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.smem);
+        // the kernel's dynamic-LDS limit is raised once (to the CU's 160 KB), not per launch
+        static const hipError_t attr_ = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_generic_kernel<T>),
+                                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)attr_;
         hipLaunchKernelGGL(conv_wgrad_generic_kernel<T>, dim3(p.gx, p.taps, p.gz), dim3(256), p.smem, s, g, (const T*)x,
                            (const T*)dy, part, bias_part, p.Ci4, p.Co4, p.nitems, p.vsplit);
     });

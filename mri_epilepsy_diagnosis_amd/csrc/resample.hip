@@ -999,8 +999,9 @@ extern "C" int mri3d_upsample3d_bwd(const Mri3dUpGeom* g, const void* dy, void* 
 #define MRI3D_UP2B(CQv)                                                                                               \
     {                                                                                                                 \
         auto kern = upsample2x_bwd_kernel<T, CQv>;                                                                    \
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,   \
-                                  (int)smem);                                                                         \
+        static const hipError_t attr_ = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),                      \
+                                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);   \
+        (void)attr_;   /* once per kernel (smem is a constant of the instantiation), not per launch */                \
         hipLaunchKernelGGL(kern, dim3(grid), dim3(256), smem, s, *g, (const T*)dy, (T*)dx, tilesD, tilesH, tilesW,    \
                            (int)nt);                                                                                  \
     }
