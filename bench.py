@@ -384,6 +384,8 @@ def main():
     profiled = "rocprof" in os.environ.get("LD_PRELOAD", "") or any(k.startswith(("ROCPROF", "ROCP_")) for k in os.environ)
     if not profiled:
         torch.cuda.synchronize()
+        import atexit
+        atexit._run_exitfuncs()   # Python-level exit hooks still run; only the native finalisers are skipped
         sys.stdout.flush()
         sys.stderr.flush()
         os._exit(0)

@@ -42,6 +42,8 @@ def pytest_unconfigure(config):
     if not (torch.cuda.is_available() and torch.cuda.is_initialized()):
         return
     torch.cuda.synchronize()
+    import atexit
+    atexit._run_exitfuncs()   # Python-level exit hooks (anyone's bookkeeping) still run; only the native finalisers are skipped
     sys.stdout.flush()
     sys.stderr.flush()
     os._exit(_exit_status[0])
