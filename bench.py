@@ -85,6 +85,112 @@ def cpu_baseline(max_seconds=25.0):
                       "of 1x%dx%dx%d fp32, torch %s, %d threads" % (len(times), C0, *SHAPE, torch.__version__, threads)}
 
 
+# classification/train_ENC_CLF.ipynb cell 17 ("93_6_4" checkpoints): the constructor arguments BASELINE configs[2] names
+AE_KWARGS_93_6_4 = dict(
+    c_in=1, is_skip=False, deapth=3, c_base=8, inc_size=2, reduce_size=False,
+    down_block_kwargs=dict(conv_k=6, conv_pad=2, conv_s=2, maxpool_k=2, maxpool_s=2, batch_norm=True, act="l_relu"),
+    up_block_kwargs=dict(up="upsample", scale=4, scale_mode="nearest", conv_k=3, conv_pad=1, conv_s=1, batch_norm=False,
+                         act="l_relu"))
+CLF_KWARGS = dict(c_in=32, c_out=64, conv_k=3, conv_s=1, conv_pad=1, l_in=64 * 2 * 3 * 2, l_out=32, batch_norm=True, act="relu",
+                  p_drop=0.5, n_class=2)   # conv_pad=1 / l_in=768: the shipped pad-0 head only fits 192^3
+
+
+def secondary_benchmarks(device, steps=10, warmup=3):
+    """The other BASELINE.json configurations on this GPU, measured AFTER the headline's timed region (never inside it): each one
+    a training step (zero_grad + forward + loss + backward replayed as one hipGraph, then the fused flat Adam), `warmup` untimed
+    and `steps` timed replays between two device synchronisations.  `roofline_ms` is SURVEY §8d / BASELINE.md §4's per-unit
+    roofline time x the units of one step; `frac` = roofline_ms / ms_per_step.  Returns {name: {...}}; a configuration that
+    fails is reported with its error instead of a number (the headline line is never lost to a secondary)."""
+    import torch
+    import torch.nn.functional as F
+    from mri_epilepsy_diagnosis_amd import ops, parallel
+    from mri_epilepsy_diagnosis_amd.classification.models import AE_model, cnn_model
+    from mri_epilepsy_diagnosis_amd.segmentation.models.modified_3dunet import Modified3DUNet
+
+    def randn(*shape, seed=0):
+        return torch.randn(*shape, device=device, generator=torch.Generator(device=device).manual_seed(seed))
+
+    def cfg4():
+        m = build_model(device).train()
+        x = randn(PER_GPU_BATCH, 1, *SHAPE, seed=1234)
+        t = (torch.rand(PER_GPU_BATCH, 1, *SHAPE, device=device) < 0.1).float()
+
+        def loss():
+            with ops.autocast():
+                return ops.softmax_dice_loss(m(x), t)
+        return m, loss, dict(lr=1e-3, weight_decay=1e-2, decoupled=True), PER_GPU_BATCH, "volumes/s", 2 * 1.98, \
+            "cfg4 per-GPU share: unet.UNet(c0=8) bf16 region, batch 2 x 1x160x192x160, soft-Dice + AdamW (configs[3])"
+
+    def cfg3_ae():
+        m = AE_model.AE(**AE_KWARGS_93_6_4).to(device).train()
+        x = randn(4, 1, *SHAPE, seed=3)
+        return m, (lambda: F.mse_loss(m(x), x)), dict(lr=1e-3, weight_decay=0.0, decoupled=False), 4, "volumes/s", 4 * 0.277, \
+            "cfg3 full autoencoder AE(**93_6_4) MSE step, batch 4 x 1x160x192x160 fp32 (configs[2])"
+
+    def cfg3_enc():
+        enc = AE_model.AE(**AE_KWARGS_93_6_4).enc.to(device)
+        clf = AE_model.Classificator(**CLF_KWARGS).to(device)
+        m = torch.nn.ModuleList([enc, clf]).train()
+        x = randn(4, 1, *SHAPE, seed=3)
+        y = torch.randint(0, 2, (4,), device=device)
+        return m, (lambda: F.cross_entropy(clf(enc(x)[0]), y)), dict(lr=7e-4, weight_decay=1e-4, decoupled=False), 4, \
+            "volumes/s", 4 * 0.105, "cfg3 encoder + classifier head CE step, batch 4 x 1x160x192x160 fp32 (configs[2])"
+
+    def cfg5():
+        m = torch.nn.Sequential(cnn_model.CNN(input_shape=(32, 32, 32), n_filters=16, n_blocks=3),
+                                torch.nn.Linear(128, 2)).to(device).train()
+        x = randn(512, 1, 32, 32, 32, seed=5)
+        y = torch.randint(0, 2, (512,), device=device)
+        return m, (lambda: F.cross_entropy(m(x), y)), dict(lr=1e-5, weight_decay=0.01, decoupled=False), 512, "patches/s", \
+            512 * 0.0286, "cfg5 stand-in: CNN(32^3, 16 filters, 3 blocks) + Linear CE step, batch 512 fp32 (configs[4])"
+
+    def m3d():
+        m = Modified3DUNet(1, 2, 8).to(device).train()
+        x = randn(1, 1, *SHAPE, seed=6)
+        t = (torch.rand(1, 1, *SHAPE, device=device) < 0.1).float()
+        return m, (lambda: ops.softmax_dice_loss(m(x), t)), dict(lr=1e-3, weight_decay=1e-2, decoupled=True), 1, "volumes/s", \
+            7.37, "Modified3DUNet(1,2,8) soft-Dice + AdamW step, batch 1 x 1x160x192x160 fp32 (SURVEY a10)"
+
+    out = {}
+    for name, make in (("cfg4_bf16", cfg4), ("cfg3_autoencoder", cfg3_ae), ("cfg3_encoder_head", cfg3_enc), ("cfg5_patch_cnn", cfg5),
+                       ("modified3dunet", m3d)):
+        cap = None
+        try:
+            torch.manual_seed(0)
+            model, loss_fn, okw, units, unit, roof_ms, what = make()
+            flat = parallel.FlatParams(model)
+            opt = parallel.FlatAdam(flat, **okw)
+            cap = parallel.CapturedStep(flat, loss_fn).capture()
+
+            def step():
+                cap.run()
+                opt.step(flat.all_reduce())
+            for _ in range(warmup):
+                step()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                step()
+            torch.cuda.synchronize()
+            ms = (time.perf_counter() - t0) / steps * 1e3
+            lv = cap.loss.item()
+            out[name] = {"workload": what, "ms_per_step": round(ms, 3), "value": round(units / ms * 1e3, 2), "unit": unit,
+                         "steps": steps, "warmup": warmup, "roofline_ms": round(roof_ms, 3), "frac": round(roof_ms / ms, 4),
+                         "launch": "hipGraph(fwd+bwd) + AdamW", "final_loss": round(lv, 6)}
+            del model, loss_fn, flat, opt, step
+        except Exception as e:  # noqa: BLE001 — reported in the line, the headline survives
+            out[name] = {"error": "%s: %s" % (type(e).__name__, e)}
+            torch.cuda.synchronize()
+        finally:
+            if cap is not None:
+                cap.release()
+            cap = None
+            import gc
+            gc.collect()
+            torch.cuda.empty_cache()
+    return out
+
+
 def launch_ranks(n, argv):
     """`python bench.py --gpus N` (N > 1) without a torchrun environment: this process becomes a pure launcher.  It has not
     imported torch and never touches the GPU (no os.exec of a GPU process either): it starts
@@ -117,6 +223,14 @@ def launch_ranks(n, argv):
     print(lines[0], flush=True)
 
 
+def rank_plan(rank, local_rank, rehearsal=False):
+    """What a rank of the N-rank run uses: its device (cuda:LOCAL_RANK — one process per GPU; cuda:0 for every rank in the
+    one-GPU rehearsal) and the seed of its synthetic volumes (1234 + rank: every rank trains on different data).
+    The single place both main() and --launch-check read it from, so the CPU suite checks the mapping the real run uses."""
+    return {"rank": int(rank), "local_rank": int(local_rank), "device_index": 0 if rehearsal else int(local_rank),
+            "data_seed": 1234 + int(rank)}
+
+
 def launch_check(args):
     """--launch-check: the N-rank plumbing only (rendezvous, barrier, MAX all-reduce, one JSON line from rank 0), no model
     and no kernels — what the CPU suite can drive without a GPU (gloo).  Its line carries "launch_check": true and no value."""
@@ -130,17 +244,23 @@ def launch_check(args):
     dev = torch.device("cuda", local) if backend == "nccl" else torch.device("cpu")
     seen = torch.ones(1, device=dev, dtype=torch.float64)
     tt = torch.tensor([float(rank + 1)], device=dev, dtype=torch.float64)
+    plan = rank_plan(rank, local, os.environ.get("MRI3D_BENCH_ONE_GPU_REHEARSAL") == "1")
+    plans = [plan]
     if world > 1:
-        dist.barrier()
+        parallel.barrier(local if backend == "nccl" else None)
         dist.all_reduce(seen, op=dist.ReduceOp.SUM)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        mine = torch.tensor([plan["rank"], plan["local_rank"], plan["device_index"], plan["data_seed"]], device=dev, dtype=torch.int64)
+        got = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(got, mine)
+        plans = [dict(zip(("rank", "local_rank", "device_index", "data_seed"), (int(v) for v in g.tolist()))) for g in got]
     if rank == 0:
         print(json.dumps({"launch_check": True, "metric": "MRI volumes/sec (fwd+bwd) 3D U-Net @160x192x160", "value": None,
                           "n_gpus": world, "ranks_seen": dist.get_world_size() if world > 1 else 1,
-                          "ranks_counted_by_all_reduce": int(seen.item()), "max_over_ranks": tt.item(),
+                          "ranks_counted_by_all_reduce": int(seen.item()), "max_over_ranks": tt.item(), "rank_plans": plans,
                           "backend": backend if world > 1 else None}), flush=True)
     if world > 1:
-        dist.barrier()
+        parallel.barrier(local if backend == "nccl" else None)
         dist.destroy_process_group()
 
 
@@ -150,6 +270,8 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true",
+                    help="skip the `secondary` object (the other BASELINE configurations, measured after the timed region)")
     ap.add_argument("--dtype", choices=("f32", "bf16"), default="f32")
     ap.add_argument("--graph", choices=("auto", "on", "off"), default="auto",
                     help="replay forward+backward as one captured hipGraph.  auto = off for f32 (GPU-bound, and the "
@@ -191,13 +313,14 @@ def main():
     ranks_seen = torch.distributed.get_world_size() if world > 1 else 1
     if ranks_seen != args.gpus:
         raise SystemExit("--gpus %d but the process group has %d ranks" % (args.gpus, ranks_seen))
-    device = torch.device("cuda", 0 if rehearsal else local)
+    plan = rank_plan(rank, local, rehearsal)
+    device = torch.device("cuda", plan["device_index"])
     torch.cuda.set_device(device)
 
     model = build_model(device)
     flat = parallel.FlatParams(model)
     opt = parallel.FlatAdam(flat, lr=1e-3, weight_decay=1e-2, decoupled=True)  # torch.optim.AdamW defaults
-    g = torch.Generator(device=device).manual_seed(1234 + rank)
+    g = torch.Generator(device=device).manual_seed(plan["data_seed"])
     x = torch.randn(PER_GPU_BATCH, 1, *SHAPE, device=device, generator=g)
     t = (torch.rand(PER_GPU_BATCH, 1, *SHAPE, device=device, generator=g) < 0.1).float()
     model.train()
@@ -227,8 +350,7 @@ def main():
         return loss
 
     def barrier():
-        if world > 1:
-            torch.distributed.barrier()
+        parallel.barrier(None if rehearsal else local)
         torch.cuda.synchronize()
 
     # Eager launches (default, f32).  The per-operator table comes from the last (up to two) WARM-UP steps, where every C-ABI call
@@ -373,22 +495,22 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline and not bf16:
             out["cpu_baseline"] = cpu_baseline()
+        if world == 1 and not args.no_secondary and not bf16:
+            # the timed region is over and `value` is final: the other configurations run now, on the same device, one by one
+            del x, t
+            out["secondary"] = secondary_benchmarks(device)
         print(json.dumps(out), flush=True)
     if world > 1:
-        torch.distributed.barrier()
+        parallel.barrier(None if rehearsal else local)
         torch.distributed.destroy_process_group()
-    # The line is out and every rank is done: leave without the interpreter's finalisers.  (One GPU test session of round 2 died
-    # with SIGABRT in torch / HIP runtime teardown after its work was complete; a bench run that has already printed its result
-    # should not be turned into a failure by that.)
-    # (not under a profiler: rocprofv3 writes its tables from exit handlers that os._exit would skip)
-    profiled = "rocprof" in os.environ.get("LD_PRELOAD", "") or any(k.startswith(("ROCPROF", "ROCP_")) for k in os.environ)
-    if not profiled:
-        torch.cuda.synchronize()
-        import atexit
-        atexit._run_exitfuncs()   # Python-level exit hooks still run; only the native finalisers are skipped
-        sys.stdout.flush()
-        sys.stderr.flush()
-        os._exit(0)
+    # Explicit teardown while the HIP runtime is alive, then an ordinary exit (round 2 left through os._exit here): the captured
+    # graph and its private pool, the event pairs of the operator timers and the scratch buffers go now, not in whatever order
+    # interpreter finalisation finds them.
+    del timer, table
+    cap.release()
+    parallel.release_captured_graphs()
+    ops.release_workspaces()
+    torch.cuda.synchronize()
 
 
 if __name__ == "__main__":

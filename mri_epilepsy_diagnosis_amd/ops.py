@@ -202,6 +202,11 @@ def _workspace(nbytes, device):
     return ws
 
 
+def release_workspaces():
+    """Drop the scratch buffers (explicit teardown; they are re-created on demand)."""
+    _workspaces.clear()
+
+
 class KernelTimer:
     """Optional per-operator device timing: when installed (bench.py), every C-ABI call made through `_timed` is
     bracketed by two events recorded on the stream the kernels are enqueued on (torch's current stream)."""

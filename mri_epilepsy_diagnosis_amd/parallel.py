@@ -9,12 +9,44 @@ the 1/world_size averaging folded into the fused optimizer step (`FlatAdam`).
 and the optimizer each touch a single allocation.  BatchNorm statistics stay local to each rank by default (the
 per-GPU batch is what the reference's single-GPU batch was); this is stated in DESIGN.md.
 """
+import atexit
 import ctypes
+import gc
+import weakref
 
 import torch
 import torch.distributed as dist
 
 from . import _lib, ops
+
+# Every object that owns a captured hipGraph (StepCache entries, CapturedStep) is registered here so that the graphs — and the
+# private allocator pools their activations live in — can be destroyed EXPLICITLY while the HIP runtime is alive
+# (`release_captured_graphs`, also run as an atexit hook).  A StepCache hangs on its model and refers back to it: such a cycle
+# is only collected by the cyclic GC, which for a model that lives until the end of the program means interpreter finalisation
+# — after which the order of graph-exec destruction against the runtime's own static teardown is nobody's to choose
+# (DESIGN.md §5, "teardown").
+_graph_owners = weakref.WeakSet()
+
+
+def release_captured_graphs():
+    """Destroy every captured hipGraph of this process now (StepCache entries and CapturedStep graphs), on a quiet device.
+    The owners stay usable: a StepCache re-captures on its next run, a CapturedStep falls back to eager launches until
+    `capture()` is called again.  Idempotent; registered with `atexit` so that no graph survives into interpreter finalisation."""
+    owners = list(_graph_owners)
+    if not owners:
+        return
+    cuda_up = torch.cuda.is_available() and torch.cuda.is_initialized()
+    if cuda_up:
+        torch.cuda.synchronize()
+    for o in owners:
+        o.release()
+    del owners
+    gc.collect()
+    if cuda_up:
+        torch.cuda.synchronize()
+
+
+atexit.register(release_captured_graphs)
 
 
 class FlatParams:
@@ -132,12 +164,29 @@ def init_from_env(backend=None):
     if world > 1 and not dist.is_initialized():
         if backend is None:
             backend = "nccl" if torch.cuda.is_available() else "gloo"
-        if backend == "nccl":
-            torch.cuda.set_device(local)
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
-        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+        if backend == "nccl":
+            # RCCL: bind the rank to its device BEFORE the group exists and hand the device to the group, so that the
+            # communicator is created eagerly on that device (no lazy first-collective guess, no barrier() on "the current
+            # device" of a rank that has not selected one yet)
+            torch.cuda.set_device(local)
+            dist.init_process_group(backend=backend, rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend=backend, rank=rank, world_size=world)
     return rank, local, world
+
+
+def barrier(local_rank=None, group=None):
+    """dist.barrier() that names the rank's device for the RCCL backend (a device-less NCCL barrier picks a device by rank
+    modulo device count and warns / can hang when that is not the rank's own); a no-op without a process group."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) <= 1:
+        return
+    if dist.get_backend(group) == "nccl":
+        dev = torch.cuda.current_device() if local_rank is None else int(local_rank)
+        dist.barrier(group=group, device_ids=[dev])
+    else:
+        dist.barrier(group=group)
 
 
 def shard_range(n_items, rank, world):
@@ -167,6 +216,14 @@ class CapturedStep:
         self.graph = None
         self.loss = None
         self.warmup = warmup
+        _graph_owners.add(self)
+
+    def release(self):
+        """Drop the captured graph (and the static loss tensor that lives in its pool); `run()` launches eagerly afterwards."""
+        self.graph = None
+        self.loss = None
+
+    reset = release
 
     def _eager(self):
         self.flat.zero_grad()
@@ -232,6 +289,13 @@ class StepCache:
         self.entries = {}
         self.disabled = False
         self.replays = self.captures = self.eager_runs = 0
+        _graph_owners.add(self)
+
+    def clear(self):
+        """Drop every captured entry (graphs, static inputs / outputs, their allocator pools); the next run() re-captures."""
+        self.entries.clear()
+
+    release = clear
 
     @staticmethod
     def of(model):

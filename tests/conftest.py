@@ -23,30 +23,43 @@ def pytest_collection_modifyitems(config, items):
             item.add_marker(skip)
 
 
-_exit_status = [None]
+_fault_log = [None]
+
+
+def pytest_sessionstart(session):
+    """GPU sessions keep a faulthandler file (gpurun_out/faulthandler_pytest.log, merged back by gpurun): if the process ever
+    dies on a signal — the one SIGABRT of round 2 left nothing behind — the Python stacks of all threads are in it."""
+    import torch
+    if not torch.cuda.is_available():
+        return
+    import faulthandler
+    out = os.path.join(ROOT, "gpurun_out")
+    try:
+        os.makedirs(out, exist_ok=True)
+        _fault_log[0] = open(os.path.join(out, "faulthandler_pytest.log"), "w")
+        faulthandler.enable(file=_fault_log[0], all_threads=True)
+    except OSError:
+        faulthandler.enable()
 
 
 def pytest_sessionfinish(session, exitstatus):
-    _exit_status[0] = int(exitstatus)
-
-
-@pytest.hookimpl(trylast=True)
-def pytest_unconfigure(config):
-    """Leave a GPU session through os._exit once pytest has reported.  One run on the GPU box ended with SIGABRT (rc 134) at about
-    the time its last test finishes (its output was lost; the same tests passed in every other run, before and after) — consistent
-    with an abort in interpreter teardown (torch / HIP runtime finalisers), which this removes.  The session's exit status is final
-    here, so nothing is hidden: a failing or crashing TEST still fails the run.  CPU sessions exit normally."""
-    if _exit_status[0] is None or "torch" not in sys.modules:
+    """Explicit teardown while the HIP runtime is alive (round 2 left through os._exit instead, after one unexplained SIGABRT at
+    the end of a green run): every captured hipGraph — `parallel.StepCache` hangs them on models in a model <-> cache cycle that
+    only the cyclic GC of interpreter finalisation would break — is destroyed here on a quiet device, the operator timer and the
+    per-stream workspaces are dropped, and the process then exits the ordinary way."""
+    if "torch" not in sys.modules:
         return
     import torch
     if not (torch.cuda.is_available() and torch.cuda.is_initialized()):
         return
+    import gc
+    from mri_epilepsy_diagnosis_amd import ops, parallel
+    ops.set_timer(None)
+    parallel.release_captured_graphs()
+    ops.release_workspaces()
+    gc.collect()
     torch.cuda.synchronize()
-    import atexit
-    atexit._run_exitfuncs()   # Python-level exit hooks (anyone's bookkeeping) still run; only the native finalisers are skipped
-    sys.stdout.flush()
-    sys.stderr.flush()
-    os._exit(_exit_status[0])
+    torch.cuda.empty_cache()
 
 
 @pytest.fixture(scope="session")

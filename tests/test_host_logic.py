@@ -201,6 +201,21 @@ def test_bench_gpus_n_launches_its_own_ranks():
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["ranks_seen"] == 2 and out["ranks_counted_by_all_reduce"] == 2
     assert out["max_over_ranks"] == 2.0 and out["backend"] == "gloo" and out["launch_check"] is True
+    # every child maps LOCAL_RANK -> its own device and draws its volumes from seed 1234 + rank (bench.rank_plan, the function
+    # main() reads the same two things from)
+    assert out["rank_plans"] == [{"rank": r, "local_rank": r, "device_index": r, "data_seed": 1234 + r} for r in range(2)]
+
+
+def test_bench_rank_plan_and_barrier_helper():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    b = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(b)
+    assert b.rank_plan(3, 3) == {"rank": 3, "local_rank": 3, "device_index": 3, "data_seed": 1237}
+    assert b.rank_plan(3, 3, rehearsal=True)["device_index"] == 0
+    from mri_epilepsy_diagnosis_amd import parallel
+    parallel.barrier(0)          # no process group: a no-op, not an error
+    parallel.release_captured_graphs()   # nothing captured: a no-op
 
 
 def test_bench_refuses_a_world_size_that_is_not_gpus():
