@@ -95,6 +95,19 @@ int mri3d_conv3d_dgrad_cat(const Mri3dConvGeom* g, const void* dy, const void* w
 int mri3d_conv3d_wgrad_cat(const Mri3dConvGeom* g, const void* x, const void* x2, int32_t split, int32_t x2_ld, const void* dy,
                            void* dw, void* dbias, void* workspace, size_t ws_bytes, mri3d_stream_t stream);
 
+/* The d-marching forward / data-gradient kernel BY NAME (csrc/conv_march.hip; nn.Conv3d 3x3x3 / stride 1 / pad 1 of `unet.UNet`,
+ * segmentation/routine.py:346-356).  mri3d_conv3d_fwd / _dgrad / _fwd_stats / _fwd_cat / _dgrad_cat choose it themselves for the
+ * layers it is faster on; these entry points take every geometry it can compute (mri3d_conv3d_march_supported(g, pass) = 1), so a
+ * caller — the parity tests — reaches it with any volume.  x2 / dx2 may be NULL (one tensor; split, *_ld ignored); stat_partials may
+ * be NULL, else [mri3d_conv3d_march_stats_blocks(g)][co][2].  Workspace: mri3d_conv3d_workspace_bytes of the pass. */
+int32_t mri3d_conv3d_march_supported(const Mri3dConvGeom* g, int32_t pass);
+int32_t mri3d_conv3d_march_stats_blocks(const Mri3dConvGeom* g);
+int mri3d_conv3d_fwd_march(const Mri3dConvGeom* g, const void* x, const void* x2, int32_t split, int32_t x2_ld, const void* w,
+                           const void* bias, void* y, double* stat_partials, void* workspace, size_t ws_bytes,
+                           mri3d_stream_t stream);
+int mri3d_conv3d_dgrad_march(const Mri3dConvGeom* g, const void* dy, const void* w, void* dx, void* dx2, int32_t split,
+                             int32_t dx2_ld, void* workspace, size_t ws_bytes, mri3d_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------------
  * BatchNorm3d / InstanceNorm3d fused with the following activation — replaces
  * nn.BatchNorm3d + nn.PReLU (unet.UNet ConvolutionalBlock), nn.BatchNorm3d + LeakyReLU/ReLU

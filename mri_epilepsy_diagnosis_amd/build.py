@@ -12,14 +12,14 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(HERE, "csrc", "build")
 LIB = os.path.join(HERE, "libmri3d_hip.so")
-SOURCES = ["api.hip", "conv_generic.hip", "conv_mfma.hip", "conv_pointwise.hip", "norm.hip", "resample.hip", "loss.hip", "elementwise.hip", "preprocess.hip", "surface.hip", "patches.hip"]
+SOURCES = ["api.hip", "conv_generic.hip", "conv_mfma.hip", "conv_march.hip", "conv_pointwise.hip", "norm.hip", "resample.hip", "loss.hip", "elementwise.hip", "preprocess.hip", "surface.hip", "patches.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function"]
 
 
 def _digest(path):
     h = hashlib.sha256()
-    for dep in [path, os.path.join(CSRC, "common.h"), os.path.join(HERE, "..", "include", "mri3d.h")]:
+    for dep in [path, os.path.join(CSRC, "common.h"), os.path.join(CSRC, "mfma_util.h"), os.path.join(HERE, "..", "include", "mri3d.h")]:
         with open(dep, "rb") as f:
             h.update(f.read())
     h.update(" ".join(FLAGS).encode())
@@ -103,7 +103,7 @@ def build_host_sanitizer(verbose=True):
     flags = ["--offload-arch=gfx950", "-fsanitize=address,undefined", "-fno-gpu-sanitize", "-fno-sanitize-recover=undefined", "-fno-omit-frame-pointer",
              "-O1", "-g", "-std=c++17", "-w", "-I", os.path.join(root, "include")]
     h = hashlib.sha256(" ".join(flags).encode())
-    inputs = [os.path.join(CSRC, s) for s in SOURCES] + [os.path.join(CSRC, "common.h"), os.path.join(root, "include", "mri3d.h"), driver]
+    inputs = [os.path.join(CSRC, s) for s in SOURCES] + [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "mfma_util.h"), os.path.join(root, "include", "mri3d.h"), driver]
     for f in inputs:
         with open(f, "rb") as fh:
             h.update(fh.read())

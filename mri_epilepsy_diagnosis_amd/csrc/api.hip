@@ -43,6 +43,12 @@ int conv_mfma_wgrad_cat(const Mri3dConvGeom& g, const void* x, const void* x2, i
 int conv_mfma_fwd_stats(const Mri3dConvGeom& g, const void* x, const float* w, const float* bias, void* y, double* stat_part,
                         void* ws, size_t ws_bytes, hipStream_t s);
 
+// conv_march.hip
+bool conv_march_takes(const Mri3dConvGeom& g, bool dgrad, bool stats, bool force);
+int conv_march_stat_blocks(const Mri3dConvGeom& g, bool force);
+int conv_march_run(const Mri3dConvGeom& g, bool dgrad, bool force, const void* in_v, const float* w, const float* bias, void* out_v,
+                   void* ws, size_t ws_bytes, hipStream_t s, double* stat_part, const void* second, int split, int second_ld);
+
 // conv_pointwise.hip
 bool conv_pointwise_supported(const Mri3dConvGeom& g, int pass);
 size_t conv_pointwise_workspace_bytes(const Mri3dConvGeom& g, int pass);
@@ -174,6 +180,39 @@ extern "C" int mri3d_conv3d_wgrad_cat(const Mri3dConvGeom* g, const void* x, con
                   MRI3D_ENOTSUP, "conv3d_wgrad_cat: geometry / alignment not served (query mri3d_conv3d_cat_supported)");
     return conv_mfma_wgrad_cat(*g, x, x2, split, x2_ld, dy, (float*)dw, (float*)dbias, workspace, ws_bytes,
                                static_cast<hipStream_t>(stream));
+}
+
+// ---- the d-marching forward / data-gradient kernel by name (conv_march.hip).  The plain entry points above choose it themselves for
+// the layers it is faster on; these take EVERY geometry it can compute, so that parity tests reach it with small volumes.
+extern "C" int32_t mri3d_conv3d_march_supported(const Mri3dConvGeom* g, int32_t pass) {
+    if (!g || (pass != MRI3D_PASS_FWD && pass != MRI3D_PASS_DGRAD) || conv_check(g, "conv3d_march_supported") != MRI3D_OK) return 0;
+    return conv_march_takes(*g, pass == MRI3D_PASS_DGRAD, false, true) ? 1 : 0;
+}
+
+extern "C" int32_t mri3d_conv3d_march_stats_blocks(const Mri3dConvGeom* g) {
+    if (!g || conv_check(g, "conv3d_march_stats_blocks") != MRI3D_OK) return 0;
+    return conv_march_stat_blocks(*g, true);
+}
+
+extern "C" int mri3d_conv3d_fwd_march(const Mri3dConvGeom* g, const void* x, const void* x2, int32_t split, int32_t x2_ld,
+                                      const void* w, const void* bias, void* y, double* stat_partials, void* workspace,
+                                      size_t ws_bytes, mri3d_stream_t stream) {
+    int rc = conv_check(g, "conv3d_fwd_march", x2 ? split : -1);
+    if (rc) return rc;
+    MRI3D_REQUIRE(x && w && y, MRI3D_EINVAL, "conv3d_fwd_march: null pointer");
+    MRI3D_REQUIRE(x2 == nullptr || (split > 0 && split < g->ci && x2_ld >= g->ci - split), MRI3D_EINVAL, "conv3d_fwd_march: bad split");
+    return conv_march_run(*g, false, true, x, (const float*)w, (const float*)bias, y, workspace, ws_bytes,
+                          static_cast<hipStream_t>(stream), stat_partials, x2, split, x2_ld);
+}
+
+extern "C" int mri3d_conv3d_dgrad_march(const Mri3dConvGeom* g, const void* dy, const void* w, void* dx, void* dx2, int32_t split,
+                                        int32_t dx2_ld, void* workspace, size_t ws_bytes, mri3d_stream_t stream) {
+    int rc = conv_check(g, "conv3d_dgrad_march", dx2 ? split : -1);
+    if (rc) return rc;
+    MRI3D_REQUIRE(dy && w && dx, MRI3D_EINVAL, "conv3d_dgrad_march: null pointer");
+    MRI3D_REQUIRE(dx2 == nullptr || (split > 0 && split < g->ci && dx2_ld >= g->ci - split), MRI3D_EINVAL, "conv3d_dgrad_march: bad split");
+    return conv_march_run(*g, true, true, dy, (const float*)w, nullptr, dx, workspace, ws_bytes, static_cast<hipStream_t>(stream),
+                          nullptr, dx2, split, dx2_ld);
 }
 
 extern "C" int mri3d_conv3d_wgrad(const Mri3dConvGeom* g, const void* x, const void* dy, void* dw, void* dbias,

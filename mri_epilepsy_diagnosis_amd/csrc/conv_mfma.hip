@@ -19,12 +19,19 @@
 // Roofline: compute-bound for Cin*Cout >= 8*16 (AI 72..270 FLOP/B vs ridge ~20): the bound is the fp32
 // MFMA peak; algorithmic FLOPs = 2 * N*D*H*W * Cin * Cout * 27 per pass.
 #include "common.h"
+#include "mfma_util.h"
 #include <stdlib.h>
 #include <type_traits>
 
 namespace mri3d {
 
-typedef float f32x4 __attribute__((ext_vector_type(4)));
+// conv_march.hip: forward / data gradient marching along d.  `force` = the explicit entry points (every geometry the kernel can
+// compute); otherwise the dispatcher's own choice of the layers where it is the faster kernel.
+bool conv_march_takes(const Mri3dConvGeom& g, bool dgrad, bool stats, bool force);
+size_t conv_march_workspace_bytes(const Mri3dConvGeom& g, bool dgrad);
+int conv_march_stat_blocks(const Mri3dConvGeom& g, bool force);
+int conv_march_run(const Mri3dConvGeom& g, bool dgrad, bool force, const void* in_v, const float* w, const float* bias, void* out_v,
+                   void* ws, size_t ws_bytes, hipStream_t s, double* stat_part, const void* second, int split, int second_ld);
 
 constexpr int TD = 4, TH = 8, TW = 16;               // output tile (d, h, w)
 constexpr int HD = TD + 2, HH = TH + 2, HW = TW + 2;  // halo tile
@@ -42,13 +49,6 @@ __host__ __device__ constexpr int tap_groups(int CK) { return CK == 16 ? 27 : 14
 __host__ __device__ constexpr int pair_tap(int tg, int half) {
     return tg < 9 ? ((tg / 3) * 3 + tg % 3) * 3 + half
                   : (tg < 12 ? (half * 3 + (tg - 9)) * 3 + 2 : (tg == 12 ? (6 + half) * 3 + 2 : (half == 0 ? 26 : 27)));
-}
-
-// Bijective XCD-aware remap (cdna_hip_programming.md T1): blocks b and b+8 share an XCD; give each XCD a contiguous
-// range of tiles so that spatial neighbours (which share halo voxels) hit the same L2.
-__device__ __forceinline__ int xcd_remap(int b, int n) {
-    const int q = n >> 3, r = n & 7, xcd = b & 7;
-    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
 }
 
 // ------------------------------------------------------------------ weight packing
@@ -183,40 +183,14 @@ extern "C" void mri3d_debug_block_spans(unsigned long long* out) {
 //       of one voxel per lane and the epilogue is a fully coalesced 16-byte store per lane (1 KiB per wave).
 constexpr int kStg = (HVOX * 2 + 255) / 256;  // 16-byte staging pieces per lane per 8-channel chunk (9)
 
-typedef int i32x4 __attribute__((ext_vector_type(4)));
 #ifndef MRI3D_DMA_PPT
 #define MRI3D_DMA_PPT 1   // DMA pieces issued per tap group (9 pieces per chunk)
 #endif
-
-// One LDS-DMA piece (`buffer_load_dwordx4 ... offen lds`): lane l's 16 bytes at byte offset `voff` of the buffer resource `rs`
-// land at LDS byte address lds_dst + 16*l (lds_dst wave-uniform: a wave-instruction fills 1 KiB); an offset >= num_records
-// writes ZEROS.  No VGPR destination, no ds_write.  Semantics probed on the hardware by tools/microbench/lds_dma_probe.hip
-// (incl. LDS addresses above 64 KiB).  The load is invisible to hipcc's s_waitcnt bookkeeping: the kernel waits for its DMA
-// pieces itself (a counted vmcnt in front of the chunk barrier); hipcc's own counts stay conservative-correct because VMEM
-// returns in order.  M0 (the LDS base of the DMA) is compiler-reserved: saved and restored inside the statement.
-__device__ __forceinline__ void lds_dma16(unsigned voff, i32x4 rs, unsigned lds_dst) {
-    unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep)
-                 : "v"(voff), "s"(rs), "s"(lds_dst)
-                 : "memory");
-}
-constexpr unsigned kDmaOob = 0xffffff80u;      // >= kDmaRecords: an out-of-volume piece (zeros)
-constexpr unsigned kDmaRecords = 0xffffff00u;  // num_records of the per-item resource (its base is the item's halo origin)
 
 // T = float: 8-channel chunks, four 16x16x4 fp32 MFMAs per tap group.  T = bf16_t: the SAME byte geometry (a 32-byte voxel
 // slice = 16 channels, 16-byte pieces, identical staging and LDS addressing) with one v_mfma_f32_16x16x32_bf16 per tap
 // group; the kernel is then bound by the LDS operand reads (the bf16 3x3x3 layers are memory-bound).
 // `wp` is the packed weight image (fp32 or bf16), addressed in 16-byte fragments.
-// sum over the 16 lanes of a DPP row (lanes with equal lane >> 4): four row rotations, every lane ends with the total
-__device__ __forceinline__ float row_sum16(float v) {
-    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x128, 0xf, 0xf, false));   // row_ror:8
-    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x124, 0xf, 0xf, false));   // row_ror:4
-    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x122, 0xf, 0xf, false));   // row_ror:2
-    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x121, 0xf, 0xf, false));   // row_ror:1
-    return v;
-}
-
 // STATS (forward only): the epilogue also accumulates, per output channel, sum(a) and sum(a^2) of the convolution result a
 // WITHOUT its bias over the voxels of the volume — the BatchNorm batch statistics of y = a + bias (shift = bias), so that the
 // statistics pass over y (one full read of every conv output, 0.5 ms per step of the U-Net) is not needed.  fp32 over a wave's
@@ -1111,6 +1085,10 @@ static int run_mfma_fwd(const Mri3dConvGeom& g, bool dgrad, const void* in_v, co
     MfmaFwdPlan p;
     DirectPlan dp;
     const bool strided = direct_only(g);
+    // the layers the marching kernel is faster on (bf16 tensors on a chip-filling grid): conv_march.hip
+    if (!strided && conv_march_takes(g, dgrad, stat_part != nullptr, false) &&
+        (sp.second == nullptr || (sp.split % 16 == 0 && sp.second_ld % 8 == 0)))
+        return conv_march_run(g, dgrad, false, in_v, w, bias, out_v, ws, ws_bytes, s, stat_part, sp.second, sp.split, sp.second_ld);
     if (strided) {
         MRI3D_REQUIRE(direct_plan(g, dgrad, dp) && stat_part == nullptr, MRI3D_ENOTSUP, "conv3d(mfma): unsupported strided geometry");
         p.small = 1;
@@ -1187,6 +1165,7 @@ int conv_mfma_fwd(const Mri3dConvGeom& g, const void* x, const float* w, const f
 
 // number of per-workgroup statistics partials the forward kernel writes for this geometry (0: not served by the MFMA path)
 int conv_mfma_fwd_stat_blocks(const Mri3dConvGeom& g) {
+    if (!direct_only(g) && conv_march_takes(g, false, true, false)) return conv_march_stat_blocks(g, false);
     MfmaFwdPlan p;
     if (!mfma_fwd_plan(g, false, p) || p.NTT > 8 || p.narrow) return 0;   // LDS statistics slots for up to 128 output channels
     return p.grid;
@@ -2724,8 +2703,10 @@ size_t conv_mfma_workspace_bytes(const Mri3dConvGeom& g, int pass) {
     MfmaWgradPlan q;
     DirectPlan dp;
     if (pass != MRI3D_PASS_WGRAD && direct_only(g)) return direct_plan(g, pass == MRI3D_PASS_DGRAD, dp) ? dp.wp_floats * sizeof(float) : 0;
-    if (pass == MRI3D_PASS_FWD && mfma_fwd_plan(g, false, p)) return std::max(p.wp_floats, p.s_wp_floats) * sizeof(float);
-    if (pass == MRI3D_PASS_DGRAD && mfma_fwd_plan(g, true, p)) return std::max(p.wp_floats, p.s_wp_floats) * sizeof(float);
+    if (pass == MRI3D_PASS_FWD && mfma_fwd_plan(g, false, p))
+        return std::max(std::max(p.wp_floats, p.s_wp_floats) * sizeof(float), conv_march_workspace_bytes(g, false));
+    if (pass == MRI3D_PASS_DGRAD && mfma_fwd_plan(g, true, p))
+        return std::max(std::max(p.wp_floats, p.s_wp_floats) * sizeof(float), conv_march_workspace_bytes(g, true));
     if (pass == MRI3D_PASS_WGRAD && mfma_wgrad_plan(g, q)) return q.part_floats * sizeof(float);
     return 0;
 }

@@ -71,6 +71,32 @@ for _ in range(4):
 torch.cuda.synchronize()
 gc_events = []
 gc.callbacks.append(lambda phase, info: gc_events.append((phase, info.get("generation"), time.perf_counter())))
+if len(sys.argv) > 3 and sys.argv[3] == "nosync":
+    # the model_bench regime: steps issued back to back, the host free to run ahead of the device, every event kept alive
+    state["on"] = True
+    t_all0 = time.perf_counter()
+    marks = []
+    for s in range(steps):
+        marks.append((len(log), time.perf_counter()))
+        step()
+    t_host = time.perf_counter() - t_all0
+    torch.cuda.synchronize()
+    t_wall = time.perf_counter() - t_all0
+    state["on"] = False
+    print("== %d steps back to back: host issue %.2f ms/step, wall %.2f ms/step, %d brackets" % (steps, t_host * 1e3 / steps, t_wall * 1e3 / steps, len(log)))
+    rows = []
+    prev_exit = t_all0
+    for i, (tag, t0, t1, e0, e1) in enumerate(log):
+        stp = max(k for k, (n0, _) in enumerate(marks) if n0 <= i)
+        rows.append((e0.elapsed_time(e1), (t0 - prev_exit) * 1e3, (t1 - t0) * 1e3, stp, i - marks[stp][0], tag))
+        prev_exit = t1
+    print("   brackets by device time:")
+    for devms, gap, body, stp, idx, tag in sorted(rows, key=lambda r: -r[0])[:8]:
+        print("   step %d bracket #%3d  device %8.3f ms  host gap before %7.3f ms  host body %7.3f ms  %s" % (stp, idx, devms, gap, body, tag))
+    print("   brackets by host time (gap before + body):")
+    for devms, gap, body, stp, idx, tag in sorted(rows, key=lambda r: -(r[1] + r[2]))[:8]:
+        print("   step %d bracket #%3d  device %8.3f ms  host gap before %7.3f ms  host body %7.3f ms  %s" % (stp, idx, devms, gap, body, tag))
+    sys.exit(0)
 for s in range(steps):
     log.clear()
     gc_events.clear()
