@@ -15,6 +15,10 @@ LIB = os.path.join(HERE, "libmri3d_hip.so")
 SOURCES = ["api.hip", "conv_generic.hip", "conv_mfma.hip", "conv_march.hip", "conv_pointwise.hip", "norm.hip", "resample.hip", "loss.hip", "elementwise.hip", "preprocess.hip", "surface.hip", "patches.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function"]
+# per-file additions.  conv_march.hip keeps its accumulators in a[0:95] BY NAME (inline asm): hipcc must never park a VGPR in an
+# AGPR there (it would pick a0.. and be overwritten by the MFMAs) — its own VGPR -> AGPR spilling is switched off, and
+# tests/test_march_codegen.py checks the generated code for stray AGPR writes and scratch use.
+EXTRA_FLAGS = {"conv_march.hip": ["-mllvm", "-amdgpu-spill-vgpr-to-agpr=0"]}
 
 
 def _digest(path):
@@ -22,7 +26,7 @@ def _digest(path):
     for dep in [path, os.path.join(CSRC, "common.h"), os.path.join(CSRC, "mfma_util.h"), os.path.join(HERE, "..", "include", "mri3d.h")]:
         with open(dep, "rb") as f:
             h.update(f.read())
-    h.update(" ".join(FLAGS).encode())
+    h.update(" ".join(FLAGS + EXTRA_FLAGS.get(os.path.basename(path), [])).encode())
     return h.hexdigest()
 
 
@@ -33,7 +37,7 @@ def _compile(src):
     dig = _digest(path)
     if os.path.exists(obj) and os.path.exists(stamp) and open(stamp).read() == dig:
         return obj, False
-    cmd = [HIPCC] + FLAGS + ["-c", path, "-o", obj]
+    cmd = [HIPCC] + FLAGS + EXTRA_FLAGS.get(src, []) + ["-c", path, "-o", obj]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=900)
     if r.returncode != 0:
         raise RuntimeError("hipcc failed for %s:\n%s\n%s" % (src, r.stdout, r.stderr))
@@ -74,7 +78,7 @@ def build_variant(name, extra_flags, verbose=True):
 
     def one(src):
         obj = os.path.join(obj_dir, src.replace(".hip", ".o"))
-        r = subprocess.run([HIPCC] + FLAGS + ["-DMRI3D_TUNING"] + list(extra_flags) + ["-c", os.path.join(CSRC, src), "-o", obj],
+        r = subprocess.run([HIPCC] + FLAGS + EXTRA_FLAGS.get(src, []) + ["-DMRI3D_TUNING"] + list(extra_flags) + ["-c", os.path.join(CSRC, src), "-o", obj],
                            capture_output=True, text=True, timeout=900)
         if r.returncode != 0:
             raise RuntimeError("hipcc failed for %s:\n%s" % (src, r.stderr[-3000:]))

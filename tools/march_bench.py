@@ -48,6 +48,7 @@ def main():
     reps = int(opt("--reps", "20"))
     names = opt("--layers", ",".join(LAYERS)).split(",")
     n = int(opt("--batch", "2"))
+    warm = float(opt("--warm", "1.5"))   # seconds of back-to-back launches before the first measurement (the chip's clock settles)
     L = _lib.lib()
     dev = torch.device("cuda")
     CL = torch.channels_last_3d
@@ -88,6 +89,14 @@ def main():
 
         flops = 2.0 * n * co * ci * 27 * d * h * w
         nbytes = float(n * d * h * w * (ci + co) * esz)
+        if warm > 0 and fwd() == 0:
+            import time
+            t0 = time.perf_counter()
+            while time.perf_counter() - t0 < warm:
+                for _ in range(50):
+                    fwd()
+                torch.cuda.synchronize()
+            warm = 0.25   # later layers: a short refresher
         for pname, fn in (("fwd", fwd), ("dgrad", dgrad)):
             rc = fn()
             if rc != 0:
@@ -95,6 +104,9 @@ def main():
                 continue
             fn()
             torch.cuda.synchronize()
+            stamps = getattr(L, "mri3d_debug_march_stamps", None)   # -DMRI3D_EXPERIMENT_STAMPS builds only
+            if stamps is not None:
+                stamps(None, 1)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             for _ in range(reps):
@@ -104,6 +116,24 @@ def main():
             ms = e0.elapsed_time(e1) / reps
             print("%-12s %-5s %3d->%-3d @%dx%dx%d: %7.3f ms  %7.1f TFLOP/s  %7.1f GB/s" % (name, pname, ci, co, d, h, w, ms, flops / ms / 1e9, nbytes / ms / 1e6),
                   flush=True)
+            if stamps is not None:   # wave 0 of workgroup 0: shader clocks per item in retire (store + rotate) / DMA wait / the 15 groups
+                buf = (ctypes.c_ulonglong * 8)()
+                stamps(buf, 0)
+                items = max(1, buf[3])
+                print("      stamps/item (%d items per launch): retire %.0f  dma-wait %.0f  groups %.0f  | whole march %.0f clk/item, clock %.2f GHz"
+                      % (items // reps, buf[0] / items, buf[1] / items, buf[2] / items, buf[6] / items, buf[6] / max(1, buf[7]) * 0.1), flush=True)
+                spans = getattr(L, "mri3d_debug_march_spans", None)
+                if spans is not None:   # when do the workgroups of the last launch start and end their march (100 MHz ticks)?
+                    import numpy as np
+                    sb = (ctypes.c_ulonglong * 4096)()
+                    spans(sb)
+                    a = np.array(sb[:], dtype=np.int64).reshape(1024, 4)
+                    a = a[a[:, 2] > 0]
+                    t0 = a[:, 0].min()
+                    ent, st_, en = (a[:, 0] - t0) / 100.0, (a[:, 1] - t0) / 100.0, (a[:, 2] - t0) / 100.0
+                    print("      %d workgroups: kernel entry (us) median %.1f max %.1f | march start median %.1f max %.1f | march end min %.1f p10 %.1f median %.1f p90 %.1f max %.1f | march length min %.1f median %.1f max %.1f"
+                          % (len(a), np.median(ent), ent.max(), np.median(st_), st_.max(), en.min(), np.percentile(en, 10), np.median(en), np.percentile(en, 90), en.max(),
+                             (en - st_).min(), np.median(en - st_), (en - st_).max()), flush=True)
         del xa, xb, dy, y, dxa, dxb
 
 
