@@ -359,8 +359,17 @@ def main():
     # step 1 % (31.1 against 30.8 ms).  With no warm-up step every operator is bracketed in the timed region, as before.
     # Graph replay cannot be bracketed from the host: there the largest layer is timed right after the timed region.
     table_steps = 0 if graphed else min(2, args.warmup)
-    for _ in range(args.warmup - table_steps):
+    # two more warm-up steps run bracketed with a timer that is thrown away: the first few hundred timing events of a process make
+    # the HIP runtime grow its signal pool once — a 55-77 ms host stall inside whatever call is running (tools/host_gap_probe.py)
+    # that must not land in the table the dominant operator is chosen from
+    discard_steps = 0 if graphed else min(2, args.warmup - table_steps)
+    for _ in range(args.warmup - table_steps - discard_steps):
         step()
+    if discard_steps:
+        ops.set_timer(ops.KernelTimer())
+        for _ in range(discard_steps):
+            step()
+        ops.set_timer(None)
     table = None
     if table_steps and rank == 0:
         torch.cuda.synchronize()

@@ -70,3 +70,27 @@ def load_ckpt(name):
 def to_ncdhw(t):
     """Logical-NCDHW contiguous CPU copy of a (possibly channels-last) device tensor."""
     return t.detach().cpu().contiguous(memory_format=torch.contiguous_format)
+
+
+def kink_and_pool_margins(model64, x64):
+    """(min |x| over every PReLU input, min (largest - second largest) over every MaxPool3d(2) window) of one forward pass —
+    how far the model is from its non-differentiable points on this input."""
+    import torch.nn as nn
+    acts, pools, hooks = [], [], []
+
+    def pool_hook(mod, inp, out):
+        x = inp[0].detach()
+        n, c, d, h, w = x.shape
+        win = x.view(n, c, d // 2, 2, h // 2, 2, w // 2, 2).permute(0, 1, 2, 4, 6, 3, 5, 7).reshape(n, c, d // 2, h // 2, w // 2, 8)
+        top = win.topk(2, dim=-1).values
+        pools.append((top[..., 0] - top[..., 1]).min().item())
+    for mod in model64.modules():
+        if isinstance(mod, nn.PReLU):
+            hooks.append(mod.register_forward_hook(lambda mo, inp, out: acts.append(inp[0].detach().abs().min().item())))
+        elif isinstance(mod, nn.MaxPool3d):
+            hooks.append(mod.register_forward_hook(pool_hook))
+    with torch.no_grad():
+        model64(x64)
+    for h in hooks:
+        h.remove()
+    return min(acts), min(pools)
