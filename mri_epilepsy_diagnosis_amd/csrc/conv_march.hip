@@ -670,7 +670,9 @@ bool conv_march_plan(const Mri3dConvGeom& g, bool dgrad, bool stats, bool force,
 #if defined(MRI3D_NO_MARCH)   // tuning builds (tools/march_bench.py --lib): the round-2 dispatcher, tiled kernel everywhere
     return false;
 #endif
-    if (!bf) return false;
+    // fp32: the tiled kernel is MFMA-bound like this one; the march is 2-3 % ahead on the full-resolution layers with 16 output
+    // channels per pass (16 -> 16 128.5 against 126.3, 16 -> 48 data gradient 130.1 against 127.4 TFLOP/s) and behind elsewhere
+    if (!bf && (Nc % 16 != 0 || (int64_t)g.n * g.di * g.hi * g.wi < (int64_t)4 << 20)) return false;
     if (grid < 192 || beste < 0.70) return false;
     // one 16-channel output block per pass: wider outputs re-stage the input once per block, which only pays for the data
     // gradient of the decoder's 16 -> 48 layer (the tiled kernel makes three passes there too)
