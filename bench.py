@@ -446,16 +446,16 @@ def main():
             achieved, peak, unit, bound = work["bytes"] / avg_s / 1e9, PEAK_HBM_GBS, "GB/s", "hbm"
         # HBM-side traffic per launch of the dominant kernel.  PMC counters cannot be read from inside this process, so this is
         # NOT a measurement of this run: it is the committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE record (separate passes,
-        # tools/pmc_conv.sh) of the same kernel on the same geometry, with FETCH_SIZE x 2 as calibrated on this library's
+        # tools/pmc_conv.sh, round 3) of the same kernel on the same geometry, with FETCH_SIZE x 2 as calibrated on this library's
         # access shapes (profiles/r02_fetch_size_calibration.txt).  `traffic_source` says so in the line itself; null if the
         # dominant operator has no record.
         traffic, traffic_source = None, None
         try:
-            with open(os.path.join(ROOT, "profiles", "r02_hbm_traffic_48_16.json")) as f:
+            with open(os.path.join(ROOT, "profiles", "r03_hbm_traffic_48_16.json")) as f:
                 rec = json.load(f).get(dom_tag.replace(" +bn-stats", ""))
             if rec:
                 traffic = round(rec["traffic_bytes"])
-                traffic_source = "profiles/r02_hbm_traffic_48_16.json (rocprofv3 --pmc, separate run of this kernel and geometry; 2 x FETCH_SIZE + WRITE_SIZE)"
+                traffic_source = "profiles/r03_hbm_traffic_48_16.json (rocprofv3 --pmc, separate run of this kernel and geometry; 2 x FETCH_SIZE + WRITE_SIZE)"
         except (OSError, ValueError):
             pass
         roofline = {"bound": bound, "achieved": round(achieved, 3), "peak": peak, "unit": unit,
