@@ -327,11 +327,7 @@ __device__ __forceinline__ void conv_march_body(const T* __restrict__ x, const T
         const unsigned lane_off = kBf16 ? (unsigned)(li * yld + 8 * (kq & 1)) + (kq >> 1) * row_step : (unsigned)(li * yld + 4 * sg);
         const bool lane_ok = (kBf16 ? nb * 16 + 8 * (kq & 1) : co) < q.Nc && w0 + li < W;
         const int row_par = kBf16 ? (kq >> 1) : 0;   // the row of a pair this lane stores
-#if defined(MRI3D_EXPERIMENT_NO_STORE)
-        const int nstores = 0;
-#else
         const int nstores = (h0 + MH <= H) ? (kBf16 ? MH / 2 : MH) : 0;   // store instructions per plane that certainly issue (wave-uniform)
-#endif
         // BatchNorm batch statistics of a = y - bias: per-lane fp32 sums over the column's planes (at most 8 rows x seglen values
         // per lane), reduced over the 16 voxel lanes and handed on in float64 once, at the end of the march
         f32x2 s1a = f32x2{0.f, 0.f}, s1b = f32x2{0.f, 0.f}, s2a = f32x2{0.f, 0.f}, s2b = f32x2{0.f, 0.f};
@@ -372,12 +368,8 @@ __device__ __forceinline__ void conv_march_body(const T* __restrict__ x, const T
                     // half exchange: lanes 0-31 end with (own row m, partner's row m), lanes 32-63 with (partner's row m+1, own row m+1)
                     auto rx = __builtin_amdgcn_permlane32_swap(p00, p10, false, false);
                     auto ry = __builtin_amdgcn_permlane32_swap(p01, p11, false, false);
-#if defined(MRI3D_EXPERIMENT_NO_STORE)   // tuning builds: the plane is packed, nothing is written (results are wrong)
-                    asm volatile("" ::"v"(rx[0]), "v"(ry[0]), "v"(rx[1]), "v"(ry[1]));
-#else
                     if (lane_ok && h0 + m + row_par < H)
                         *reinterpret_cast<uint4*>(ytile + (lane_off + (unsigned)m * row_step)) = make_uint4(rx[0], ry[0], rx[1], ry[1]);
-#endif
                 } else if (lane_ok) {   // the plan guarantees Nc % 4 == 0 and a pitch of whole quads: one vector store per row
                     if constexpr (BIAS) {
                         if (h0 + m < H) {   // wave-uniform

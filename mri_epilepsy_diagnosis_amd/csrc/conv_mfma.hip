@@ -271,10 +271,6 @@ conv_mfma_fwd2_kernel(const T* __restrict__ x, const float* __restrict__ wp, con
     struct Item { int n, d0, h0, w0, nt0, ch; };
     auto decode = [&](int it) -> Item {
         Item r;
-#if defined(MRI3D_EXPERIMENT_NO_DECODE)   // timing ablation: no divisions (every item is the same interior tile: results are wrong)
-        r.ch = nchunks == 1 ? 0 : it % nchunks; r.nt0 = 0; r.w0 = TW; r.h0 = TH; r.d0 = TD; r.n = 0;
-        return r;
-#endif
         int tile = r_lo + wslot + (it / nchunks) * wper;
         r.ch = it % nchunks;
         r.nt0 = (tile % gy) * NT;
@@ -336,12 +332,8 @@ conv_mfma_fwd2_kernel(const T* __restrict__ x, const float* __restrict__ wp, con
         const T* xs = second ? x2 : x;
         const int ld = second ? x2_ld : x_ld, c0 = second ? it.ch * CK - ksplit : it.ch * CK;
         st.ldb = (unsigned)ld * (unsigned)sizeof(T);
-#if defined(MRI3D_EXPERIMENT_SAME_TILE)   // every item stages the same (interior) tile: all pieces are L2 hits, no fabric traffic
-        const unsigned long long org = (unsigned long long)(xs + ((((int64_t)(TD - 1) * H + TH - 1) * W + TW - 1) * ld + c0));
-#else
         const unsigned long long org =
             (unsigned long long)(xs + (((((int64_t)it.n * D + it.d0 - 1) * H + it.h0 - 1) * W + it.w0 - 1) * ld + c0));
-#endif
         // raw buffer resource: base (48 bits), stride 0, num_records, gfx9 raw-dword format
         st.rs[0] = __builtin_amdgcn_readfirstlane((int)(unsigned)(org & 0xffffffffu));
         st.rs[1] = __builtin_amdgcn_readfirstlane((int)(unsigned)((org >> 32) & 0xffffu));
@@ -377,13 +369,6 @@ conv_mfma_fwd2_kernel(const T* __restrict__ x, const float* __restrict__ wp, con
     };
     const size_t wstep = (size_t)NTT * 256;
 
-#if defined(MRI3D_EXPERIMENT_DESYNC)   // tuning: delay the second workgroup of every CU by MRI3D_EXPERIMENT_DESYNC x 64 cycles
-    // (measured: no gain on any layer, profiles/r02_workgroup_exit_times.txt — the two workgroups of a CU do not run in lock step)
-    if (blockIdx.x >= (gridDim.x + 1) / 2) {
-        for (int i = 0; i < (MRI3D_EXPERIMENT_DESYNC) / 100; ++i) __builtin_amdgcn_s_sleep(100);
-        __builtin_amdgcn_s_sleep((MRI3D_EXPERIMENT_DESYNC) % 100);
-    }
-#endif
 #if defined(MRI3D_EXPERIMENT_STAMPS)   // the clock the chip holds in this kernel: shader cycles / 100 MHz reference ticks
     const unsigned long long clk0 = __builtin_amdgcn_s_memtime(), ref0 = __builtin_amdgcn_s_memrealtime();
     unsigned long long stamp_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -442,8 +427,6 @@ conv_mfma_fwd2_kernel(const T* __restrict__ x, const float* __restrict__ wp, con
             if (cur.ch + 1 < nchunks) nxt.ch = cur.ch + 1;
             else nxt = advance(cur);
         }
-        // MRI3D_EXPERIMENT_*: timing ablations of tuning builds (python -m mri_epilepsy_diagnosis_amd.build --variant ...;
-        // results are wrong): see DESIGN.md §4.2 for the measured table.
         if constexpr (N8) {
             const Stage stn = stage_open(nxt, (it + 1) & 1, has_next);
             const float* wtn = weights_of(nxt);
@@ -507,11 +490,7 @@ conv_mfma_fwd2_kernel(const T* __restrict__ x, const float* __restrict__ wp, con
             // groups come in UNITS: four classes of three groups that differ only by one halo row (pair_tap), then groups 12
             // and 13.  A class needs 10 row fragments (rows 0..9 of its kh = 0 group; group kh, output row m uses row m + kh)
             // instead of 3 x 8; the next unit's fragments are fetched while this unit is multiplied (two register sets).
-#if !defined(MRI3D_EXPERIMENT_NO_STAGING)
             const Stage stn = stage_open(nxt, (it + 1) & 1, has_next);   // the next chunk: 9 DMA pieces per lane, landed by the barrier
-#else
-            const Stage stn = stage_open(nxt, (it + 1) & 1, false);
-#endif
             const float* wtn = weights_of(nxt);             // (the last item re-reads its own: the loads stay unconditional)
             constexpr int NU = 6;
             f32x4 fr[2][TH + 2];
@@ -525,12 +504,7 @@ conv_mfma_fwd2_kernel(const T* __restrict__ x, const float* __restrict__ wp, con
                 const int u = tg < 12 ? tg / 3 : tg - 8, ufirst = u < 4 ? 3 * u : u + 8, ng = u < 4 ? 3 : 1;
                 const int kh = tg - ufirst;   // row shift inside the class (0 for the single-group units)
                 stage_group(nxt, stn, tg);
-#if !defined(MRI3D_EXPERIMENT_NO_WLOAD)
                 if (tg >= 1) bqa[tg - 1] = *reinterpret_cast<const f32x4*>(wtn + (size_t)(tg - 1) * wstep);   // next item's
-#endif
-#if defined(MRI3D_EXPERIMENT_NO_AFRAG)
-                if (false)
-#endif
                 if (u + 1 < NU) {   // this group's share of the next unit's fragments
                     const int nu = u + 1, nfirst = nu < 4 ? 3 * nu : nu + 8, nf = nu < 4 ? TH + 2 : TH;
                     const int on = a_off(nfirst);
@@ -558,9 +532,7 @@ conv_mfma_fwd2_kernel(const T* __restrict__ x, const float* __restrict__ wp, con
                         }
                 }
             }
-#if !defined(MRI3D_EXPERIMENT_NO_WLOAD)
             bqa[TG - 1] = *reinterpret_cast<const f32x4*>(wtn + (size_t)(TG - 1) * wstep);
-#endif
         } else {
         // Two N-tiles: a 3-deep ring of weight fragments (two tap groups of lead).  The ring is primed BEFORE the DMA pieces are
         // issued, so that the first tap group does not wait for them; the loads of tap groups 2.. queue behind the pieces,
@@ -652,11 +624,7 @@ conv_mfma_fwd2_kernel(const T* __restrict__ x, const float* __restrict__ wp, con
                             for (int m = 0; m < TH; ++m) {
                                 if (cur.h0 + m < H) {   // wave-uniform
                                     const f32x4 a = acc[m][nt];
-#if defined(MRI3D_EXPERIMENT_NO_STORE)   // tuning builds: the sums are formed, nothing is written
-                                    asm volatile("" ::"v"(a[0] + bv.x), "v"(a[1] + bv.y), "v"(a[2] + bv.z), "v"(a[3] + bv.w));
-#else
                                     stf4(ytile + (lane_off + (unsigned)m * row_step), make_float4(a[0] + bv.x, a[1] + bv.y, a[2] + bv.z, a[3] + bv.w));
-#endif
                                 }
                             }
                         } else {
@@ -722,9 +690,7 @@ conv_mfma_fwd2_kernel(const T* __restrict__ x, const float* __restrict__ wp, con
         asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kYounger) : "memory");
         MRI3D_STAMP(t_wait);
         MRI3D_STAMP_ADD(2, t_epi, t_wait);
-#if !defined(MRI3D_EXPERIMENT_NO_CHUNK_BARRIER)   // tuning builds only: timing ablation, results are wrong without it
         __syncthreads();  // buffer (it+1)&1 is complete; buffer it&1 may be overwritten from the next iteration on
-#endif
         MRI3D_STAMP(t_bar);
         MRI3D_STAMP_ADD(3, t_wait, t_bar);
         MRI3D_STAMP_ADD(4, t_item, t_bar);
@@ -1056,7 +1022,7 @@ static bool mfma_fwd_plan(const Mri3dConvGeom& g, bool dgrad, MfmaFwdPlan& p) {
     const int64_t nvox = (int64_t)g.n * g.di * g.hi * g.wi;
     DirectPlan dp;
 #ifndef MRI3D_SMALL_UNITS
-#define MRI3D_SMALL_UNITS 512   // one work unit per workgroup slot or fewer.  Measured (tools/small_units_ab.sh): 256 -> 512 moves 32 -> 32
+#define MRI3D_SMALL_UNITS 512   // one work unit per workgroup slot or fewer.  Measured (tools/small_units_ab.sh, variants -DMRI3D_SMALL_UNITS=N): 256 -> 512 moves 32 -> 32
 #endif                          // @ 40x48x40 x 2 from 64 to 72 and 64 -> 64 @ 40x48x40 from 68 to 80 TFLOP/s; 1024 loses on 32 -> 64 (85 -> 79)
     if (!bf && st < MRI3D_SMALL_UNITS && nvox * Kc * 4 <= ((int64_t)32 << 20) && direct_plan(g, dgrad, dp)) {   // bf16 tensors stay on the bf16 MFMA
         p.small = st < 256 ? 1 : 2;   // 2: a preference only — split operands and fused statistics still take the tiled kernel
@@ -2455,16 +2421,10 @@ conv_mfma_wgrad6_kernel(const float* __restrict__ x, const float* __restrict__ d
     const TileWalk tw = tile_walk(ntiles);
     if (tw.count > 0) load_tile(tw.first);
     for (int k = 0; k < tw.count; ++k) {
-#if !defined(MRI3D_EXPERIMENT_WG6_NOSTORE)   // tuning builds: the LDS tile is written once
         __syncthreads();   // the previous tile's MFMAs are done with the LDS tile
         store_tile();
         __syncthreads();
-#else
-        if (k == 0) { store_tile(); __syncthreads(); }
-#endif
-#if !defined(MRI3D_EXPERIMENT_WG6_NOLOAD)   // tuning builds: every tile re-uses the first tile's registers (no global loads in the loop)
         load_tile(tw.first + (k + 1 < tw.count ? k + 1 : k) * tw.stride);   // (the last iteration re-reads its own tile: no branch)
-#endif
         __builtin_amdgcn_sched_barrier(0);
 
         // ---- 3 output rows per wave x 9 (kd, kh) x 3 kw x 4 k-steps
@@ -2601,13 +2561,6 @@ static bool mfma_wgrad_plan(const Mri3dConvGeom& g, MfmaWgradPlan& p) {
         p.v2 = 4;
         p.mode8 = 2 | (g.ci == 8 ? 1 : 0);
     }
-#if defined(MRI3D_EXPERIMENT_WG6_CI8)   // tuning builds: 8 -> 16k through v6 with paired X rows only (15 MFMAs per k-step against v3's
-    // 14, but v6's staging and fragment reads): 0.80 -> 0.77 ms on the U-Net's 8 -> 16 layer, 0.03 ms of a 31 ms step — not shipped
-    if (g.dtype == MRI3D_F32 && g.ci == 8 && g.co % 16 == 0 && g.y_ld % 4 == 0 && g.x_ld % 4 == 0) {
-        p.v2 = 4;
-        p.mode8 = 1;
-    }
-#endif
 #ifndef MRI3D_BF16_WGRAD_MARCH_MIN_D
 #define MRI3D_BF16_WGRAD_MARCH_MIN_D 8   // (tuning builds: a huge value keeps every bf16 layer on the tile kernel)
 #endif
