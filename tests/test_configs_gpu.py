@@ -141,7 +141,10 @@ def test_cfg5_cnn_32cube_batch64_train_step():
 
 def test_cfg5_cnn_batch512_properties_and_batch_split_consistency():
     """The whole cfg5 batch (512 patches) on one GPU: finite, deterministic run to run, and — in eval mode, where BatchNorm does
-    not couple patches — the first 64 rows equal a batch-64 forward bit for bit (N-batched tiling does not mix patches)."""
+    not couple patches — no patch's output depends on its neighbours in the batch: a permuted batch gives the permuted rows bit
+    for bit (same kernels, same per-voxel summation order), and a batch-64 forward of the first 64 patches agrees to fp32 rounding
+    (the dispatcher may pick another kernel for the smaller launch — the fp32 marching kernel takes 16-channel layers from 4 M
+    voxels — so the summation order, not the data a row sees, differs)."""
     torch.manual_seed(0)
     m = _cnn(P_CNN).to(DEV)
     g = torch.Generator(device=DEV).manual_seed(7)
@@ -165,8 +168,12 @@ def test_cfg5_cnn_batch512_properties_and_batch_split_consistency():
     m.eval()
     with torch.no_grad():
         full = m[0](x)
+        perm = torch.randperm(512, device=DEV, generator=g)
+        shuffled = m[0](x[perm].contiguous())
         part = m[0](x[:64].contiguous())
-    assert torch.equal(full[:64], part)
+    assert torch.equal(shuffled, full[perm])
+    scale = float(full.abs().max())
+    assert float((full[:64] - part).abs().max()) <= 1e-4 * scale   # fp32 rounding of another summation order, nothing more
 
 
 # ------------------------------------------------------------------------------------------------ cfg4 (bf16 region, per-GPU share)
