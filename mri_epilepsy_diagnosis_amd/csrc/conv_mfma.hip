@@ -1907,29 +1907,60 @@ conv_mfma_wgrad_bf16_kernel(const bf16_t* __restrict__ x, const bf16_t* __restri
     for (int i = tid; i < TGA * 256; i += 256) out[i] = red[i];
 }
 
-// ------------------------------------------------------------------ bf16 weight gradient, marching along d
+// ------------------------------------------------------------------ bf16 weight gradient, marching along d, staged by LDS-DMA
 // The tile kernel above re-reads its input 2.7x (a 2 x 6-row tile needs 4 x 8 rows of X) and is bound by what a CU can pull
-// through its memory pipeline (45 KB per tile in ~4 500 cycles, 10 B/clk/CU; MFMA busy 29 %).  Here a workgroup
-// owns a COLUMN of the volume — 8 rows x 32 voxels — and marches through a segment of d planes with the last planes of X in an
-// LDS ring: per output plane it fetches ONE new plane of X (10 rows) and one of dY (8 rows + the W halo), 17.5 KB instead of
-// 22.5 KB per 12 rows, and the (kd) taps read the ring.  Same transposed [channel][voxel] lines, fragments, accumulators and
-// partial layout as the tile kernel; same register staging, but two planes ahead (two register sets: the loads of step t are
-// written to LDS in step t + 2), with every per-lane address and validity fixed for the whole column.
-//   step t:  write X plane t+1 -> ring slot (t+1) & 3 and dY plane t -> buffer t & 1   (loaded in step t-2)
-//            load  X plane t+3, dY plane t+2                                             (register set t & 1)
-//            multiply plane p = t-1: X planes p-1, p, p+1 from the ring, dY plane p from buffer p & 1;   one barrier
+// through its memory pipeline (MFMA busy 29 %).  Here a workgroup owns a COLUMN of the volume — 8 rows x 32 voxels
+// — and marches through a segment of d planes with the last planes of X in an LDS ring: per output plane it fetches ONE new
+// plane of X (10 rows) and one of dY (8 rows + the W halo).  Round 2 staged the column through registers (eight 16-byte loads
+// with selected addresses, 32 v_perm of an 8x8 transpose and eight ds_write_b128 per staging lane and plane): ~100 vector
+// instructions per plane which, beside the other workgroup's MFMAs, issue only each 14-28 cycles — 4 900 cycles
+// per plane step for 1 800 cycles of MFMA work per SIMD (MFMA busy 0.30, 0.59 ms on 48 -> 16 at 2 x 160x192x160).
+// Here NO vector instruction touches the data on its way in: the rows are copied as they lie in memory (channels last: one
+// voxel = 32 bytes of a 16-channel tile) by LDS-DMA, and the transposition the MFMA needs — a lane's operand is a run of voxels
+// of ONE channel — is done by the read: ds_read_b64_tr_b16 hands lane i of a 16-lane group channel i of four consecutive voxels
+// (cdna_hip_programming.md T10).  With the address  row + 512*j + 8*lane  (j = 0, 1) a wave reads 512 contiguous bytes per
+// instruction (conflict-free), and k-group kq of the K = 32 operand holds voxels 4kq..4kq+3 and 16+4kq..16+4kq+3 of the row —
+// the same order in X and dY, so the sum over k is the sum over the row's 32 voxels.  The kw taps:
+//   dW[kd,kh,kw] = sum_v X[v + kw - 1] dY[v]  =  sum_u X[u] dY[u + 1 - kw]
+// i.e. dY read one voxel (32 bytes) to the left / right: an address, not a shuffle; the sums are re-partitioned between
+// W-neighbouring columns — a column takes the products of ITS X voxels, with dY[w0-1] and dY[w0+32] read from the neighbours
+// (zero outside the volume) — so X has no W halo and dY a one-voxel one.  Tasks = (sample, d-segment, column); accumulators
+// (27 taps x (16 ci x 16 co) per wave, +1 for dbias fed with A = 1) and partial layout as in the tile kernel.
+//   LDS: X planes in a ring of five (10 rows x 1 KiB), dY planes in a ring of three (8 rows x 34 voxels, 1 088 B per row).
+//   step t:  wait for the wave's pieces of step t-2 (counted vmcnt: the pieces of step t-1 may still fly), barrier,
+//            issue X plane t+3 and dY plane t+2 (19 pieces of 1 KiB per workgroup, 5 or 4 per wave, per-lane offsets constant
+//            for the column; a plane outside the segment's range is a resource of zero records: zeros),
+//            multiply plane t: X planes t-1, t, t+1, dY plane t.
+// Measured against the register-staged kernel (tools/r03_wgt.sh, one box): 48 -> 16 0.590 -> 0.503 ms, 16 -> 16 0.232 -> 0.195,
+// 8 -> 16 0.215 -> 0.180, 96 -> 32 at 80x96x80 0.358 -> 0.302, 16 -> 16 at 512 x 32^3 0.333 -> 0.287.  What binds it now is the
+// fabric: with the MFMAs compiled out the 48 -> 16 layer still takes 0.415 ms (its three ci-tile workgroups each fetch dY: PMC
+// 2.0x the algorithmic bytes, 5 TB/s), with the DMA compiled out 0.280 ms; with every workgroup on one L2-resident column the
+// DMA alone runs at 14 TB/s.  (Workgroups of one task's ci-tiles share an XCD — tools/microbench/xcc_probe.hip — yet run in lock
+// step and miss together; a start skew does not survive, the follower catches up.)
 constexpr int MTH = 8, MXR = MTH + 2;                 // output rows / X rows per plane
-constexpr int MXP = MXR * 16 * DLS;                   // 10 240 B  one X plane
-constexpr int MXS = 4 * MXP;                          // ring of four planes
-constexpr int MYP = MTH * 16 * DLS;                   //  8 192 B  one dY plane
-constexpr int MYS = 2 * MYP;
-constexpr int MHP = MTH * 16 * 8;                     //  1 024 B  W halo of one dY plane
-constexpr int MYH = 2 * MHP;
 constexpr int kMarchSeg = 40;                         // planes per task at most (4 fill steps per task); shorter for small volumes
+constexpr int TXROW = BTW * 32;                       //  1 024 B  one X row: 32 voxels x 16 channels
+constexpr int TXP = MXR * TXROW;                      // 10 240 B  one X plane
+constexpr int TXSLOTS = 5;
+constexpr int TYROW = (BTW + 2) * 32;                 //  1 088 B  one dY row with its two W-halo voxels
+constexpr int TYPIECES = (MTH * TYROW + 1023) / 1024; //  9 pieces of 1 KiB (the ninth: lanes 0..31)
+constexpr int TYP = TYPIECES * 1024;                  //  9 216 B  one dY plane (8 704 used)
+constexpr int TYSLOTS = 3;
+constexpr int TLDS = TXSLOTS * TXP + TYSLOTS * TYP;   // 78 848 B: two workgroups per CU
+constexpr int TNPC = (MXR + TYPIECES + 3) / 4;        // DMA pieces per wave and step at most (5)
+
+typedef short s16x4_t __attribute__((ext_vector_type(4)));
+// the K = 32 operand of the lane from a raw [voxel][16 channels] row: `a` = LDS byte address of the row + 8 * lane
+__device__ __forceinline__ bf16x8_t tr_frag(unsigned a) {
+    typedef __attribute__((address_space(3))) s16x4_t* lp;
+    const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lp)(a));
+    const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lp)(a + 512u));
+    return __builtin_bit_cast(bf16x8_t, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+}
 
 template <bool BIAS>
 __global__ void __launch_bounds__(256, 2)
-conv_mfma_wgrad_bf16m_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ dy, float* __restrict__ part, int N,
+conv_mfma_wgrad_bf16t_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ dy, float* __restrict__ part, int N,
                              int D, int H, int W, int Ci, int x_ld, int Co, int y_ld, int nseg, int tilesH, int tilesW,
                              int ntasks, const bf16_t* __restrict__ x2, int x2_ld, int ksplit, int segl) {
     constexpr int TG = 27, TGA = TG + (BIAS ? 1 : 0);
@@ -1939,9 +1970,7 @@ conv_mfma_wgrad_bf16m_kernel(const bf16_t* __restrict__ x, const bf16_t* __restr
         else xcn = ksplit;
     }
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    char* xs = reinterpret_cast<char*>(lds);
-    char* ys = xs + MXS;
-    char* yh = ys + MYS;
+    const unsigned xs0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)lds), ys0 = xs0 + TXSLOTS * TXP;
     const int cit = blockIdx.y, cob = blockIdx.z;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1954,25 +1983,10 @@ conv_mfma_wgrad_bf16m_kernel(const bf16_t* __restrict__ x, const bf16_t* __restr
 #pragma unroll
     for (int i = 0; i < 8; ++i) ones[i] = (bf16_t)1.0f;
 
-    // staging roles, one unit (8 voxels x 8 channels) per lane at most: X rows on lanes 0..79, dY rows on lanes 128..191, the
-    // dY W-halo voxels on lanes 192..223
-    const int role = tid < 80 ? 0 : (tid >= 128 && tid < 192) ? 1 : (tid >= 192 && tid < 224) ? 2 : 3;
-    const int u = role == 0 ? tid : role == 1 ? tid - 128 : tid - 192;
-    const int s_half = u & 1, s_wg = (u >> 1) & 3, s_row = u >> 3;          // roles 0, 1
-    const int h_side = (u >> 1) & 1, hy_row = u >> 2;                        // role 2
-    const bf16_t* const tens = role == 0 ? x : dy;
-    const int ld = role == 0 ? x_ld : y_ld;
-    // operand addresses of the wave's two output rows
-    const int orow0 = wv * 2;
-    const int xline0 = (orow0 * 16 + li) * DLS + 16 * rot_slot(kq, li);                 // + slot * MXP + kh * 16 * DLS
-    const int yline0 = orow0 * 16 + li;
-    const int yrow_o = yline0 * DLS + 16 * rot_slot(kq, li);                            // + buffer * MYP
-    const bool pl_halo = kq == 0, nr_halo = kq == 3;
-    const int ypl_o = pl_halo ? yline0 * 8 : yline0 * DLS + 16 * rot_slot(kq - 1, li) + 12;   // + buffer * (MHP or MYP)
-    const int ynr_o = nr_halo ? yline0 * 8 + 4 : yline0 * DLS + 16 * rot_slot(kq + 1, li);
-    const int pl_step = pl_halo ? 16 * 8 : 16 * DLS, nr_step = nr_halo ? 16 * 8 : 16 * DLS;
+    // operand addresses of the wave's two output rows (2 wv, 2 wv + 1): X rows 2 wv .. 2 wv + 3 of a plane, dY voxel u at + 32 (u + 1)
+    const unsigned xfrag = xs0 + (unsigned)(2 * wv * TXROW + 8 * lane);        // + slot * TXP + row * TXROW
+    const unsigned yfrag = ys0 + (unsigned)(2 * wv * TYROW + 32 + 8 * lane);   // + slot * TYP + row * TYROW + 32 * (1 - kw)
 
-    uint4 v[2][8];
     const TileWalk tw = tile_walk(ntasks);
     for (int k = 0; k < tw.count; ++k) {
         int task = tw.first + k * tw.stride;
@@ -1982,114 +1996,103 @@ conv_mfma_wgrad_bf16m_kernel(const bf16_t* __restrict__ x, const bf16_t* __restr
         task /= tilesH;
         const int seg = task % nseg, n = task / nseg;
         const int dA = seg * segl, dB = min(D, dA + segl);
-        // the lane's unit for this column: element offset inside a plane, valid voxels (0..8), and which planes it may touch
-        int off0 = 0, nvalid = 0;
-        if (role == 0) {
-            const int gh = h0 - 1 + s_row, c0 = xc0 + 8 * s_half;
-            if ((unsigned)gh < (unsigned)H && c0 < xcn) {
-                off0 = (gh * W + w0 + 8 * s_wg) * x_ld + c0;
-                nvalid = min(8, max(0, W - (w0 + 8 * s_wg)));
-            }
-        } else if (role == 1) {
-            const int gh = h0 + s_row, c0 = cob * 16 + 8 * s_half;
-            if (gh < H && c0 < Co) {
-                off0 = (gh * W + w0 + 8 * s_wg) * y_ld + c0;
-                nvalid = min(8, max(0, W - (w0 + 8 * s_wg)));
-            }
-        } else if (role == 2) {
-            const int gh = h0 + hy_row, gw = h_side ? w0 + BTW : w0 - 1, c0 = cob * 16 + 8 * s_half;
-            if (gh < H && (unsigned)gw < (unsigned)W && c0 < Co) {
-                off0 = (gh * W + gw) * y_ld + c0;
-                nvalid = 1;
+        const int xlo = max(dA - 1, 0), xhi = min(dB, D - 1);   // X planes the segment consumes
+
+        // the wave's pieces of a plane step: ids wv, wv + 4, ... < 19; id < 10 = X row id, else piece id - 10 of the dY plane.
+        // Byte offset of the lane's 16 bytes from the plane's origin voxel, the out-of-volume value folded in: constant for the column.
+        unsigned vof[TNPC];
+#pragma unroll
+        for (int i = 0; i < TNPC; ++i) {
+            const int id = wv + 4 * i;
+            vof[i] = kDmaOob;
+            if (id < MXR) {   // wave-uniform
+                const int vox = lane >> 1, half = lane & 1;
+                const int gh = h0 - 1 + id, gw = w0 + vox;
+                if ((unsigned)gh < (unsigned)H && gw < W && xc0 + 8 * half < xcn) vof[i] = (unsigned)(((id * W + vox) * x_ld + 8 * half) * 2);
+            } else if (id < MXR + TYPIECES) {
+                const int f = (id - MXR) * 64 + lane, row = f / (2 * (BTW + 2)), pc = f - row * (2 * (BTW + 2));
+                const int vox = pc >> 1, half = pc & 1;
+                const int gh = h0 + row, gw = w0 - 1 + vox;
+                if (row < MTH && gh < H && (unsigned)gw < (unsigned)W && cob * 16 + 8 * half < Co)
+                    vof[i] = (unsigned)(((row * W + vox) * y_ld + 8 * half) * 2);
             }
         }
-        const int64_t plane_el = (int64_t)H * W * ld;
-        const bf16_t* const tbase = tens + (int64_t)n * D * plane_el + off0;
+        // plane origins: X at (h0 - 1, w0), dY at (h0, w0 - 1); a lane whose voxel lies outside the volume never dereferences them
+        const int64_t xplane = (int64_t)H * W * x_ld * 2, yplane = (int64_t)H * W * y_ld * 2;
+        const unsigned long long xorg = (unsigned long long)(x + ((((int64_t)n * D) * H + (h0 - 1)) * W + w0) * x_ld + xc0);
+        const unsigned long long yorg = (unsigned long long)(dy + ((((int64_t)n * D) * H + h0) * W + (w0 - 1)) * y_ld + cob * 16);
 
-        auto step = [&](auto SETC, int t) {
-            constexpr int S = decltype(SETC)::value;
-            // ---- write what step t-2 loaded: X plane t+1, dY plane t (zeros where a plane or voxel does not exist)
-            if (t >= dA - 2 && t <= dB) {
-                if (role == 0) {
-                    uint4 o[8];
-                    transpose8x8_bf16(v[S], o);
-                    char* dline = xs + ((t + 1) & 3) * MXP + (s_row * 16 + 8 * s_half) * DLS + 16 * rot_slot(s_wg, 8 * s_half);
-#pragma unroll
-                    for (int c = 0; c < 8; ++c) *reinterpret_cast<uint4*>(dline + c * DLS) = o[c];
-                } else if (role == 1) {
-                    uint4 o[8];
-                    transpose8x8_bf16(v[S], o);
-                    char* yline = ys + (t & 1) * MYP + (s_row * 16 + 8 * s_half) * DLS + 16 * rot_slot(s_wg, 8 * s_half);
-#pragma unroll
-                    for (int c = 0; c < 8; ++c) *reinterpret_cast<uint4*>(yline + c * DLS) = o[c];
-                } else if (role == 2) {   // w0 - 1: high half of dword 0;  w0 + 32: low half of dword 1
-                    const unsigned* hw = reinterpret_cast<const unsigned*>(&v[S][0]);
-#pragma unroll
-                    for (int c = 0; c < 8; ++c) {
-                        const unsigned short val = (unsigned short)((c & 1) ? (hw[c >> 1] >> 16) : (hw[c >> 1] & 0xffffu));
-                        *reinterpret_cast<unsigned short*>(yh + (t & 1) * MHP + (hy_row * 16 + 8 * s_half + c) * 8 + (h_side ? 4 : 2)) = val;
-                    }
-                }
-            }
-            // ---- load X plane t+3 / dY plane t+2 (address select: a missing piece reads the zero block; nothing waits here)
-            {
-                const int pl = role == 0 ? t + 3 : t + 2;
-                const bool pok = role == 0 ? (pl >= dA - 1 && pl <= dB && (unsigned)pl < (unsigned)D) : (pl >= dA && pl < dB);
-                const bf16_t* src = tbase + (int64_t)pl * plane_el;
-#pragma unroll
-                for (int j = 0; j < 8; ++j)
-                    v[S][j] = ldg4u((pok && j < nvalid) ? src + (int64_t)j * ld : reinterpret_cast<const bf16_t*>(g_zero16));
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            // ---- multiply plane p = t - 1
-            const int p = t - 1;
-            if (p >= dA && p < dB) {
-                const char* const xb0 = xs + ((p - 1) & 3) * MXP + xline0;
-                const char* const xb1 = xs + (p & 3) * MXP + xline0;
-                const char* const xb2 = xs + ((p + 1) & 3) * MXP + xline0;
-                const char* yrow = ys + (p & 1) * MYP + yrow_o;
-                const char* ypl = (pl_halo ? yh + (p & 1) * MHP : ys + (p & 1) * MYP) + ypl_o;
-                const char* ynr = (nr_halo ? yh + (p & 1) * MHP : ys + (p & 1) * MYP) + ynr_o;
-#pragma unroll 1
-                for (int r = 0; r < 2; ++r, yrow += 16 * DLS, ypl += pl_step, ynr += nr_step) {
-                    const uint4 b1 = *reinterpret_cast<const uint4*>(yrow);            // dY[u], the lane's eight voxels
-                    const unsigned plv = *reinterpret_cast<const unsigned*>(ypl);       // high half = dY[first - 1]
-                    const unsigned nrv = *reinterpret_cast<const unsigned*>(ynr);       // low half = dY[last + 1]
-                    uint4 bm, bp;   // dY[u - 1], dY[u + 1]
-                    bm.x = __builtin_amdgcn_alignbyte(b1.x, plv, 2);
-                    bm.y = __builtin_amdgcn_alignbyte(b1.y, b1.x, 2);
-                    bm.z = __builtin_amdgcn_alignbyte(b1.z, b1.y, 2);
-                    bm.w = __builtin_amdgcn_alignbyte(b1.w, b1.z, 2);
-                    bp.x = bm.y;
-                    bp.y = bm.z;
-                    bp.z = bm.w;
-                    bp.w = __builtin_amdgcn_alignbyte(nrv, b1.w, 2);
-                    const bf16x8_t b0v = __builtin_bit_cast(bf16x8_t, bp), b1v = __builtin_bit_cast(bf16x8_t, b1),
-                                   b2v = __builtin_bit_cast(bf16x8_t, bm);
-                    if constexpr (BIAS) acc[TG] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, b1v, acc[TG], 0, 0, 0);
-                    const int rowo = r * 16 * DLS;
-#pragma unroll
-                    for (int kdh = 0; kdh < 9; ++kdh) {
-                        const char* xb = kdh < 3 ? xb0 : (kdh < 6 ? xb1 : xb2);
-                        const bf16x8_t g = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(xb + rowo + (kdh % 3) * 16 * DLS));
-                        acc[kdh * 3 + 0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(g, b0v, acc[kdh * 3 + 0], 0, 0, 0);   // X[u] dY[u+1]
-                        acc[kdh * 3 + 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(g, b1v, acc[kdh * 3 + 1], 0, 0, 0);   // X[u] dY[u]
-                        acc[kdh * 3 + 2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(g, b2v, acc[kdh * 3 + 2], 0, 0, 0);   // X[u] dY[u-1]
-                    }
-                }
-            }
-            __syncthreads();   // this step's LDS writes are visible, its reads are done
+        auto rsrc = [&](unsigned long long org, bool ok) {
+            i32x4 rs;
+            rs[0] = __builtin_amdgcn_readfirstlane((int)(unsigned)(org & 0xffffffffu));
+            rs[1] = __builtin_amdgcn_readfirstlane((int)(unsigned)((org >> 32) & 0xffffu));
+            rs[2] = ok ? (int)kDmaRecords : 0;
+            rs[3] = 0x00020000;
+            return rs;
         };
-        // steps dA-4 .. dB, two per iteration so that the register set (t & 1) is a compile-time index
-        const int t0 = (dA - 4) & ~1;
-        for (int t = t0; t <= dB; t += 2) {
-            step(std::integral_constant<int, 0>{}, t);
-            step(std::integral_constant<int, 1>{}, t + 1);
+        const int t0 = dA - 4;
+        int sx = ((t0 + 3) % TXSLOTS + TXSLOTS) % TXSLOTS;   // ring slot of X plane t + 3
+        int sy = ((t0 + 2) % TYSLOTS + TYSLOTS) % TYSLOTS;   // ring slot of dY plane t + 2
+        for (int t = t0; t < dB; ++t) {
+            // ---- the wave's pieces of step t-2 have landed (those of step t-1 are younger), then every wave's
+            if (wv == 3) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            // ---- issue X plane t+3 (its slot held plane t-2) and dY plane t+2 (its slot held plane t-1)
+            {
+                const int qx = t + 3, qy = t + 2;
+                const i32x4 rsx = rsrc(xorg + (unsigned long long)((int64_t)qx * xplane), qx >= xlo && qx <= xhi);
+                const i32x4 rsy = rsrc(yorg + (unsigned long long)((int64_t)qy * yplane), qy >= dA && qy < dB);
+                const unsigned xdst = xs0 + (unsigned)(sx * TXP), ydst = ys0 + (unsigned)(sy * TYP);
+#pragma unroll
+                for (int i = 0; i < TNPC; ++i) {
+                    const int id = wv + 4 * i;
+                    if (id < MXR) lds_dma16(vof[i], rsx, xdst + (unsigned)(id * 1024));
+                    else if (id < MXR + TYPIECES - 1) lds_dma16(vof[i], rsy, ydst + (unsigned)((id - MXR) * 1024));
+                    else if (id == MXR + TYPIECES - 1) {
+                        if (lane < (MTH * TYROW - (TYPIECES - 1) * 1024) / 16) lds_dma16(vof[i], rsy, ydst + (unsigned)((id - MXR) * 1024));
+                    }
+                }
+                sx = sx + 1 == TXSLOTS ? 0 : sx + 1;
+                sy = sy + 1 == TYSLOTS ? 0 : sy + 1;
+            }
+            // ---- multiply plane t: X plane t-1+kd is two / one / zero slots behind the one just issued ... (sx now = slot of plane t+4)
+            if (t >= dA) {
+                // slot of X plane q = (sx + q - (t + 4)) mod 5; dY plane t = (sy + t - (t + 3)) mod 3 = sy
+                const int sxm = sx;                      // plane t-1: sx - 5 = sx
+                const int sx0 = sxm + 1 >= TXSLOTS ? sxm + 1 - TXSLOTS : sxm + 1;
+                const int sx1 = sx0 + 1 >= TXSLOTS ? sx0 + 1 - TXSLOTS : sx0 + 1;
+                const unsigned yb = yfrag + (unsigned)(sy * TYP);
+                bf16x8_t dyf[2][3];
+#pragma unroll
+                for (int r = 0; r < 2; ++r)
+#pragma unroll
+                    for (int kw = 0; kw < 3; ++kw) dyf[r][kw] = tr_frag(yb + (unsigned)(r * TYROW + 32 * (1 - kw)));   // dY[u + 1 - kw]
+                if constexpr (BIAS) {
+                    acc[TG] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, dyf[0][1], acc[TG], 0, 0, 0);
+                    acc[TG] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, dyf[1][1], acc[TG], 0, 0, 0);
+                }
+#pragma unroll
+                for (int kd = 0; kd < 3; ++kd) {
+                    const unsigned xb = xfrag + (unsigned)((kd == 0 ? sxm : kd == 1 ? sx0 : sx1) * TXP);
+                    bf16x8_t xf[4];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) xf[i] = tr_frag(xb + (unsigned)(i * TXROW));
+#pragma unroll
+                    for (int r = 0; r < 2; ++r)
+#pragma unroll
+                        for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+                            for (int kw = 0; kw < 3; ++kw)
+                                acc[(kd * 3 + kh) * 3 + kw] =
+                                    __builtin_amdgcn_mfma_f32_16x16x32_bf16(xf[r + kh], dyf[r][kw], acc[(kd * 3 + kh) * 3 + kw], 0, 0, 0);
+                }
+            }
         }
     }
 
-    // combine the 4 waves in a fixed order through LDS, then one partial per workgroup
-    __syncthreads();
+    // every DMA piece has landed (the last steps' zero planes too), every wave is done reading: the ring becomes the reduction buffer
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
     float* red = lds;  // [TGA][256]
     for (int w = 0; w < 4; ++w) {
         if (wv == w) {
@@ -2564,7 +2567,7 @@ static bool mfma_wgrad_plan(const Mri3dConvGeom& g, MfmaWgradPlan& p) {
 #ifndef MRI3D_BF16_WGRAD_MARCH_MIN_D
 #define MRI3D_BF16_WGRAD_MARCH_MIN_D 8   // (tuning builds: a huge value keeps every bf16 layer on the tile kernel)
 #endif
-    // bf16, marching along d (conv_mfma_wgrad_bf16m_kernel): when the columns x segments give every workgroup at least three
+    // bf16, marching along d (conv_mfma_wgrad_bf16t_kernel): when the columns x segments give every workgroup at least three
     // tasks — segments of 40 planes, or 20 for smaller volumes (each task pays 4 staging-only fill steps; with 10-plane segments
     // the 32 -> 32 layer at 80x96x80 ran 0.132 ms against the tile kernel's 0.122)
     p.segl = 0;
@@ -2621,7 +2624,7 @@ static bool mfma_wgrad_plan(const Mri3dConvGeom& g, MfmaWgradPlan& p) {
     } else if (p.v2 == 2) {
         p.smem = std::max<size_t>((size_t)2 * V4XBUF + 2 * V4YBUF, red) * sizeof(float);
     } else if (p.v2 == 5) {
-        p.smem = std::max<size_t>((size_t)MXS + MYS + MYH, red * sizeof(float));
+        p.smem = std::max<size_t>((size_t)TLDS, red * sizeof(float));
     } else if (p.v2 >= 3) {
         p.smem = std::max<size_t>((size_t)BXS + BYS + BYH, red * sizeof(float));
     }
@@ -2694,7 +2697,7 @@ static void run_mfma_wgrad(const MfmaWgradPlan& p, const Mri3dConvGeom& g, const
             dim3 grid(p.P, p.CIT, p.COB);
 #define MRI3D_WGM(Bv)                                                                                                 \
     {                                                                                                                 \
-        auto kern = conv_mfma_wgrad_bf16m_kernel<Bv>;                                                                 \
+        auto kern = conv_mfma_wgrad_bf16t_kernel<Bv>;                                                                 \
         MRI3D_SET_SMEM_ONCE(kern, p.smem);                                                                            \
         hipLaunchKernelGGL(kern, grid, dim3(256), p.smem, s, x, dy, part, g.n, g.di, g.hi, g.wi, g.ci, g.x_ld, g.co,  \
                            g.y_ld, p.tilesD, p.tilesH, p.tilesW, p.ntiles, (const bf16_t*)sp.second, sp.second_ld,    \

@@ -79,7 +79,7 @@ def test_conv3x3x3_many_small_volumes(case, dtype):
     _run_conv_case(case, dtype)
 
 
-# bf16 weight gradient marching along d (conv_mfma_wgrad_bf16m_kernel: taken when columns x segments >= 3 tasks per workgroup): a last
+# bf16 weight gradient marching along d (conv_mfma_wgrad_bf16t_kernel, LDS-DMA rows + transposing reads: taken when columns x segments >= 3 tasks per workgroup): a last
 # segment of 5 / 3 / 1 planes, a last row tile of one row, a last column tile of 5 voxels, an 8-channel input tile (upper half
 # empty) read from a pitched buffer, 24 output channels (half-empty second block) written from a pitched gradient
 MARCH_CASES = [(8, 64, 64, 45, 17, 37, 0, 0, 91), (24, 8, 128, 23, 9, 33, 8, 0, 92), (64, 32, 24, 41, 12, 20, 0, 8, 93)]
