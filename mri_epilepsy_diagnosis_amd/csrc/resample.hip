@@ -654,6 +654,8 @@ upsample2x_bwd_march_kernel(Mri3dUpGeom g, const T* __restrict__ dy, T* __restri
         float4 accA = make_float4(0.f, 0.f, 0.f, 0.f), accB = make_float4(0.f, 0.f, 0.f, 0.f);
         T* dxo = dx + (((int64_t)n * g.di * g.hi + ih) * g.wi + iw) * g.x_ld + c0 + 4 * q;
         const int64_t xplane = (int64_t)g.hi * g.wi * g.x_ld;
+        // (A second register set — plane f+2 in flight while plane f+1 waits for its LDS write, the step barrier ordering LDS only —
+        // measured SLOWER: 0.369 -> 0.393 ms fp32, 0.225 -> 0.31 ms bf16 on the 32-channel level; the step is not one exposed round trip.)
         for (int f = f0; f <= f1; ++f) {
             if (f < f1) fetch(f + 1);
             // in-plane 4x4 taps of this lane's coarse (h, w): rows 2*ihl .. 2*ihl+3, columns 2*iwl .. 2*iwl+3 of the tile
@@ -707,101 +709,133 @@ upsample2x_bwd_march_kernel(Mri3dUpGeom g, const T* __restrict__ dy, T* __restri
     }
 }
 
-// ------------------------------------------------------------------ trilinear x2 forward, LDS-tiled
-// One lane = one coarse voxel x one channel quad: it reads its 3x3x3 coarse neighbourhood from an LDS halo tile and writes
-// the 2x2x2 fine voxels it owns (fine index 2i+e takes 0.75 of coarse i and 0.25 of coarse i-1 (e = 0) or i+1 (e = 1);
-// at the volume borders ATen's clamped source index gives the edge voxel weight 1).  The generic gather above recomputes
-// source indices and weights per fine element and reads 8 coarse voxels per 16-byte result from L2 (2.0 TB/s measured).
-constexpr int FTD = 1, FTH = 4, FTWD = 8;                 // coarse tile; 32 voxels x 8 channel quads = 256 lanes
-constexpr int FHD = FTD + 2, FHH = FTH + 2, FHW = FTWD + 2, FHV = FHD * FHH * FHW;   // 180 halo voxels
+// ------------------------------------------------------------------ trilinear x2 forward, marching along D
+// Fine index 2i+e takes 0.75 of coarse i and 0.25 of coarse i-1 (e = 0) or i+1 (e = 1).  Round 2's tile kernel (one lane = one
+// coarse voxel x channel quad writing its 2x2x2 fine voxels from a 3 x 6 x 10 clamped LDS halo) staged 180 halo voxels for the 32
+// it owned, waited, then stored — nothing overlapped, and a store instruction's lanes wrote every other fine voxel: 3.6 TB/s
+// fp32, 2.8 TB/s bf16 on the 32-channel level (0.383 / 0.25 ms; this kernel 0.283 / 0.156 ms).  The interpolation is separable: with P_c(oh, ow) = the in-plane (h, w) interpolation of coarse plane c at
+// a FINE position, fine plane 2c = 0.75 P_c + 0.25 P_{c-1} and fine plane 2c+1 = 0.75 P_c + 0.25 P_{c+1} (ATen's clamped source
+// index at the borders = a clamped coarse coordinate: 0.75 a + 0.25 a).  So a workgroup owns a 4 x 16 coarse column = 8 x 32
+// fine positions and marches along D: a lane owns FINE positions (consecutive lanes = consecutive 16-byte pieces of consecutive
+// fine voxels: a wave-store writes 1 KiB of one fine row contiguously), keeps P_{c-1} in registers, and per coarse plane reads
+// four neighbours from a clamped halo plane in LDS (6 x 18 voxels, fp32, double-buffered: the next plane's pieces are in
+// flight while this one is interpolated and stored) and stores two fine planes.  The source is read 1.7x (it is an eighth of
+// the destination), the destination written once in whole lines.
+constexpr int UTH = 4, UTW = 16;                          // coarse column (h, w)
+constexpr int UHH = UTH + 2, UHW = UTW + 2, UHV = UHH * UHW;   // clamped halo plane: 108 voxels
+constexpr int UMD = 16;                                   // coarse planes per item at most (8 / 4 for small volumes: >= 1024 items)
 
-template <typename T>
+template <typename T, int VEC, int NPV>   // VEC channels per lane item, NPV items per voxel and channel pass
 __global__ void __launch_bounds__(256)
-upsample2x_fwd_kernel(Mri3dUpGeom g, const T* __restrict__ x, T* __restrict__ y, int tilesD, int tilesH, int tilesW,
-                      int ntiles, int cpasses) {
-    __shared__ float4 cbuf[FHV * 8];   // [halo voxel][8 channel quads] = 23 KB
+upsample2x_fwd_march_kernel(Mri3dUpGeom g, const T* __restrict__ x, T* __restrict__ y, int segsD, int segl, int tilesH,
+                            int tilesW, int cpasses, int nitems) {
+    constexpr int PCH = VEC * NPV;                         // channels per pass
+    constexpr int NST = (UHV * NPV + 255) / 256;           // staged pieces per lane and plane
+    __shared__ __attribute__((aligned(16))) float cbuf[2][UHV * NPV * VEC];
     const int tid = threadIdx.x;
-    const int q = tid & 7, v = tid >> 3;
-    const int iwl = v % FTWD, ihl = (v / FTWD) % FTH;
-    for (int item = blockIdx.x; item < ntiles * cpasses; item += gridDim.x) {
-        int t = item / cpasses;
-        const int c0 = (item % cpasses) * 32;
-        const int w0 = (t % tilesW) * FTWD;
+    const int per_xcd = (nitems + 7) / 8;                  // consecutive workgroups land on different XCDs: a contiguous item range each
+    for (int b = blockIdx.x; b < per_xcd * 8; b += gridDim.x) {
+        const int item = (b % 8) * per_xcd + b / 8;
+        if (item >= nitems) continue;   // uniform per workgroup
+        int t = item;
+        const int c0 = (t % cpasses) * PCH;
+        t /= cpasses;
+        const int w0 = (t % tilesW) * UTW;
         t /= tilesW;
-        const int h0 = (t % tilesH) * FTH;
+        const int h0 = (t % tilesH) * UTH;
         t /= tilesH;
-        const int d0 = (t % tilesD) * FTD;
-        const int n = t / tilesD;
-        const T* xn = x + (int64_t)n * g.di * g.hi * g.wi * g.x_ld;
-        __syncthreads();
-        for (int idx = tid; idx < FHV * 8; idx += 256) {   // clamped coarse halo (clamping IS the border rule)
-            const int qq = idx & 7, hv = idx >> 3;
-            const int fw = hv % FHW, t2 = hv / FHW;
-            const int fh = t2 % FHH, fd = t2 / FHH;
-            const int cd = min(max(d0 - 1 + fd, 0), g.di - 1), ch = min(max(h0 - 1 + fh, 0), g.hi - 1),
-                      cw = min(max(w0 - 1 + fw, 0), g.wi - 1);
-            const int cc = c0 + 4 * qq;
-            cbuf[idx] = cc < g.c ? ldf4(xn + (((int64_t)cd * g.hi + ch) * g.wi + cw) * g.x_ld + cc) : make_float4(0.f, 0.f, 0.f, 0.f);
+        const int d0 = (t % segsD) * segl;
+        const int n = t / segsD;
+        const int d1 = min(d0 + segl, g.di);   // coarse planes [d0, d1)
+        const T* xn = x + (int64_t)n * g.di * g.hi * g.wi * g.x_ld + c0;
+        const int xplane = g.hi * g.wi * g.x_ld;
+        // the lane's staged pieces of a halo plane: element offset inside the plane (clamped coordinates: always legal)
+        int soff[NST];
+#pragma unroll
+        for (int j = 0; j < NST; ++j) {
+            const int idx = min(j * 256 + tid, UHV * NPV - 1);
+            const int pc = idx % NPV, hv = idx / NPV;
+            const int fw = hv % UHW, fh = hv / UHW;
+            const int ch = min(max(h0 - 1 + fh, 0), g.hi - 1), cw = min(max(w0 - 1 + fw, 0), g.wi - 1);
+            soff[j] = (ch * g.wi + cw) * g.x_ld + (c0 + pc * VEC < g.c ? pc * VEC : 0);
         }
-        __syncthreads();
-        const int id = d0, ih = h0 + ihl, iw = w0 + iwl;
-        // the bf16 pair exchange needs both lanes of a quad pair active (channels in whole octets) and 16-byte aligned rows
-        const bool pair_ok = sizeof(T) == 2 && (g.c & 7) == 0 && (g.y_ld & 7) == 0 && ((reinterpret_cast<uintptr_t>(y) & 15) == 0);
-        if (ih < g.hi && iw < g.wi && c0 + 4 * q < g.c) {
-            const float4* base = cbuf + ((1 * FHH + (ihl + 1)) * FHW + (iwl + 1)) * 8 + q;   // the lane's own coarse voxel
+        V<VEC> sv[NST];
+        auto fetch = [&](int c) {
+            const T* pl = xn + (int64_t)min(max(c, 0), g.di - 1) * xplane;
 #pragma unroll
-            for (int ed = 0; ed < 2; ++ed)
+            for (int j = 0; j < NST; ++j) sv[j].load(pl + soff[j]);
+        };
+        auto stash = [&](int buf) {
 #pragma unroll
-                for (int eh = 0; eh < 2; ++eh) {
-                    float4 opair[2];
+            for (int j = 0; j < NST; ++j) {
+                const int idx = j * 256 + tid;
+                if (j < NST - 1 || idx < UHV * NPV) {
 #pragma unroll
-                    for (int ew = 0; ew < 2; ++ew) {
-                        // the second source voxel per axis lies at -1 for the even fine index and +1 for the odd one; the clamped
-                        // halo makes the border case (all weight on the edge voxel) fall out of 0.75*a + 0.25*a
-                        float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-                        for (int a = 0; a < 2; ++a)
-#pragma unroll
-                            for (int b = 0; b < 2; ++b)
-#pragma unroll
-                                for (int c = 0; c < 2; ++c) {
-                                    // torch order: (d0,h0,w0),(d0,h0,w1),... with index0 = the LOWER source index
-                                    const int dd = ed ? a : a - 1, hh = eh ? b : b - 1, wwi = ew ? c : c - 1;   // offsets -1..1
-                                    const float wd = (dd == 0) ? 0.75f : 0.25f, wh = (hh == 0) ? 0.75f : 0.25f,
-                                                wq = (wwi == 0) ? 0.75f : 0.25f;
-                                    const float wgt = wd * wh * wq;
-                                    const float4 cv = base[((dd * FHH + hh) * FHW + wwi) * 8];
-                                    o.x = fmaf(wgt, cv.x, o.x);
-                                    o.y = fmaf(wgt, cv.y, o.y);
-                                    o.z = fmaf(wgt, cv.z, o.z);
-                                    o.w = fmaf(wgt, cv.w, o.w);
-                                }
-                        opair[ew] = o;
-                    }
-                    const int od = 2 * id + ed, oh = 2 * ih + eh;
-                    T* yrow = y + ((((int64_t)n * g.dout + od) * g.ho + oh) * g.wo + 2 * iw) * g.y_ld + c0;
-                    if constexpr (sizeof(T) == 2) {
-                        // bf16: a quad is 8 bytes and the two fine voxels of a pair would each get half-line pieces from separate store
-                        // instructions (partial-line writes cost up to 3.6x, tools/slice_write_probe.py).  Adjacent quad lanes swap: the
-                        // even lane keeps the ew = 0 voxel and takes its neighbour's quad of it, the odd lane the ew = 1 voxel — one
-                        // 16-byte store per lane, and the eight lanes of a coarse voxel cover its two fine voxels contiguously.
-                        if (pair_ok) {
-                            const bool odd = q & 1;
-                            const float4 send = odd ? opair[0] : opair[1], keep = odd ? opair[1] : opair[0];
-                            float4 recv;
-                            recv.x = __shfl_xor(send.x, 1, 64), recv.y = __shfl_xor(send.y, 1, 64);
-                            recv.z = __shfl_xor(send.z, 1, 64), recv.w = __shfl_xor(send.w, 1, 64);
-                            const float4 lo = odd ? recv : keep, hi = odd ? keep : recv;   // channels 4(q & ~1) .. +7 of voxel ew = odd
-                            bf16x8_t o8;
-                            o8[0] = (bf16_t)lo.x, o8[1] = (bf16_t)lo.y, o8[2] = (bf16_t)lo.z, o8[3] = (bf16_t)lo.w;
-                            o8[4] = (bf16_t)hi.x, o8[5] = (bf16_t)hi.y, o8[6] = (bf16_t)hi.z, o8[7] = (bf16_t)hi.w;
-                            *reinterpret_cast<bf16x8_t*>(yrow + (odd ? g.y_ld : 0) + 4 * (q & ~1)) = o8;
-                            continue;
-                        }
-                    }
-                    stf4(yrow + 4 * q, opair[0]);
-                    stf4(yrow + g.y_ld + 4 * q, opair[1]);
+                    for (int e = 0; e < VEC; e += 4)
+                        *reinterpret_cast<float4*>(&cbuf[buf][idx * VEC + e]) = make_float4(sv[j].v[e], sv[j].v[e + 1], sv[j].v[e + 2], sv[j].v[e + 3]);
                 }
+            }
+        };
+        // the lane's items: fine position (fhl, fwl) of the 8 x 32 tile x piece; its four coarse neighbours in the halo plane
+        int ia[NPV], ib[NPV], ic[NPV], id[NPV], yoff[NPV];
+        unsigned okm = 0;
+#pragma unroll
+        for (int k = 0; k < NPV; ++k) {
+            const int it = k * 256 + tid;
+            const int pc = it % NPV, pos = it / NPV;
+            const int fwl = pos % (2 * UTW), fhl = pos / (2 * UTW);
+            const int hw0 = (fwl >> 1) + 1, hw1 = hw0 + ((fwl & 1) ? 1 : -1), hh0 = (fhl >> 1) + 1, hh1 = hh0 + ((fhl & 1) ? 1 : -1);
+            ia[k] = ((hh0 * UHW + hw0) * NPV + pc) * VEC;   // 0.75 x 0.75
+            ib[k] = ((hh0 * UHW + hw1) * NPV + pc) * VEC;   // 0.75 x 0.25
+            ic[k] = ((hh1 * UHW + hw0) * NPV + pc) * VEC;   // 0.25 x 0.75
+            id[k] = ((hh1 * UHW + hw1) * NPV + pc) * VEC;   // 0.25 x 0.25
+            const int oh = 2 * h0 + fhl, ow = 2 * w0 + fwl;
+            const bool ok = oh < g.ho && ow < g.wo && c0 + pc * VEC < g.c;
+            okm |= ok ? (1u << k) : 0u;
+            yoff[k] = ok ? (oh * g.wo + ow) * g.y_ld + c0 + pc * VEC : 0;
+        }
+        T* yn = y + (int64_t)n * g.dout * g.ho * g.wo * g.y_ld;
+        const int64_t yplane = (int64_t)g.ho * g.wo * g.y_ld;
+
+        __syncthreads();   // the previous item's last plane is no longer being read
+        fetch(d0 - 1);
+        stash(0);
+        __syncthreads();
+        V<VEC> pp[NPV];    // P of the previous coarse plane
+        for (int c = d0 - 1; c <= d1; ++c) {
+            const int buf = (c - (d0 - 1)) & 1;
+            if (c < d1) fetch(c + 1);
+#pragma unroll
+            for (int k = 0; k < NPV; ++k) {
+                V<VEC> pc_;
+#pragma unroll
+                for (int e = 0; e < VEC; e += 4) {
+                    const float4 a = *reinterpret_cast<const float4*>(&cbuf[buf][ia[k] + e]);
+                    const float4 bq = *reinterpret_cast<const float4*>(&cbuf[buf][ib[k] + e]);
+                    const float4 cq = *reinterpret_cast<const float4*>(&cbuf[buf][ic[k] + e]);
+                    const float4 dq = *reinterpret_cast<const float4*>(&cbuf[buf][id[k] + e]);
+                    pc_.v[e + 0] = 0.75f * fmaf(0.75f, a.x, 0.25f * bq.x) + 0.25f * fmaf(0.75f, cq.x, 0.25f * dq.x);
+                    pc_.v[e + 1] = 0.75f * fmaf(0.75f, a.y, 0.25f * bq.y) + 0.25f * fmaf(0.75f, cq.y, 0.25f * dq.y);
+                    pc_.v[e + 2] = 0.75f * fmaf(0.75f, a.z, 0.25f * bq.z) + 0.25f * fmaf(0.75f, cq.z, 0.25f * dq.z);
+                    pc_.v[e + 3] = 0.75f * fmaf(0.75f, a.w, 0.25f * bq.w) + 0.25f * fmaf(0.75f, cq.w, 0.25f * dq.w);
+                }
+                if (c >= d0 && ((okm >> k) & 1u)) {
+                    V<VEC> o;
+                    if (c > d0) {        // fine plane 2(c-1)+1 = 0.75 P_{c-1} + 0.25 P_c
+#pragma unroll
+                        for (int e = 0; e < VEC; ++e) o.v[e] = fmaf(0.75f, pp[k].v[e], 0.25f * pc_.v[e]);
+                        o.store(yn + (int64_t)(2 * c - 1) * yplane + yoff[k]);
+                    }
+                    if (c < d1) {        // fine plane 2c = 0.75 P_c + 0.25 P_{c-1}
+#pragma unroll
+                        for (int e = 0; e < VEC; ++e) o.v[e] = fmaf(0.75f, pc_.v[e], 0.25f * pp[k].v[e]);
+                        o.store(yn + (int64_t)(2 * c) * yplane + yoff[k]);
+                    }
+                }
+                pp[k] = pc_;
+            }
+            if (c < d1) stash(buf ^ 1);
+            __syncthreads();
         }
     }
 }
@@ -940,16 +974,35 @@ extern "C" int mri3d_upsample3d_fwd(const Mri3dUpGeom* g, const void* x, void* y
     hipStream_t s = static_cast<hipStream_t>(stream);
     static const int no_fast_f = tuning_knob("MRI3D_UP_GENERIC", 0);   // tuning aid (A/B)
     if (!no_fast_f && up2x_fast_ok(*g) && aligned_vec4(g->dtype, x, y)) {
-        const int tilesD = cdiv(g->di, FTD), tilesH = cdiv(g->hi, FTH), tilesW = cdiv(g->wi, FTWD);
-        const int64_t nt = (int64_t)g->n * tilesD * tilesH * tilesW;
-        const int cpasses = cdiv(g->c, 32);
-        if (nt * cpasses <= 0x7fffffff) {
-            const int grid = (int)std::min<int64_t>(nt * cpasses, 8192);
-            MRI3D_DISPATCH_DTYPE(g->dtype, T, {
-                hipLaunchKernelGGL(upsample2x_fwd_kernel<T>, dim3(grid), dim3(256), 0, s, *g, (const T*)x, (T*)y, tilesD, tilesH,
-                                   tilesW, (int)nt, cpasses);
-            });
-            return check_launch("upsample3d_fwd(2x)");
+        // marching kernel: lane items of 16 bytes where the tensors allow it (bf16: channels and pitches in whole octets)
+        const bool oct = g->dtype == MRI3D_BF16 && g->c % 8 == 0 && g->x_ld % 8 == 0 && g->y_ld % 8 == 0 &&
+                         ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y)) & 15) == 0;
+        const int vec = oct ? 8 : 4, pieces = g->c / vec;
+        const int npv = pieces >= 8 ? 8 : pieces >= 4 ? 4 : pieces >= 2 ? 2 : 1;
+        const int mtilesH = cdiv(g->hi, UTH), mtilesW = cdiv(g->wi, UTW), mpasses = cdiv(pieces, npv);
+        int segl = UMD;   // every segment stages two planes more than it owns: long segments unless the grid would not fill the chip
+        while (segl > 4 && (int64_t)g->n * cdiv(g->di, segl) * mpasses * mtilesH * mtilesW < 1024) segl /= 2;
+        const int segsD = cdiv(g->di, segl);
+        const int64_t items = (int64_t)g->n * segsD * mpasses * mtilesH * mtilesW;
+        if (items <= 0x7ffffff0 && (int64_t)g->ho * g->wo * g->y_ld <= 0x7fffffff &&
+            (int64_t)g->hi * g->wi * g->x_ld <= 0x7fffffff) {
+            const int grid = (int)std::min<int64_t>((items + 7) / 8 * 8, 256 * 4 * 8);
+#define MRI3D_UPF(Tv, VECv, NPVv)                                                                                      \
+    hipLaunchKernelGGL((upsample2x_fwd_march_kernel<Tv, VECv, NPVv>), dim3(grid), dim3(256), 0, s, *g, (const Tv*)x,  \
+                       (Tv*)y, segsD, segl, mtilesH, mtilesW, mpasses, (int)items)
+#define MRI3D_UPF_N(Tv, VECv)                                                                                          \
+    do {                                                                                                              \
+        if (npv == 8) MRI3D_UPF(Tv, VECv, 8);                                                                         \
+        else if (npv == 4) MRI3D_UPF(Tv, VECv, 4);                                                                    \
+        else if (npv == 2) MRI3D_UPF(Tv, VECv, 2);                                                                    \
+        else MRI3D_UPF(Tv, VECv, 1);                                                                                  \
+    } while (0)
+            if (g->dtype == MRI3D_F32) MRI3D_UPF_N(float, 4);
+            else if (oct) MRI3D_UPF_N(bf16_t, 8);
+            else MRI3D_UPF_N(bf16_t, 4);
+#undef MRI3D_UPF_N
+#undef MRI3D_UPF
+            return check_launch("upsample3d_fwd(2x march)");
         }
     }
     bool v4 = vec_ok(g->dtype, g->c, g->x_ld, g->y_ld, x, y);

@@ -162,6 +162,25 @@ def test_pool_upsample_cat_add_bf16():
     _close(ag, _rb(ur.detach()) + x, "add")
 
 
+@pytest.mark.parametrize("c,sp", [(8, (5, 9, 19)), (16, (17, 4, 16)), (32, (3, 6, 33)), (64, (18, 5, 7)), (12, (4, 5, 18)), (40, (2, 9, 17))])
+def test_trilinear_x2_forward_backward_bf16(c, sp):
+    """nn.Upsample(scale_factor=2, mode='trilinear') of the U-Net decoder in the bf16 region: the marching kernels with 16-byte lane
+    items (channels in octets) and with 8-byte ones (12 channels), ragged columns, two D segments, one and two channel passes."""
+    ops = _ops()
+    torch.manual_seed(c)
+    x = _rb(torch.randn(2, c, *sp))
+    xr = x.clone().requires_grad_(True)
+    ur = F.interpolate(xr, scale_factor=2, mode="trilinear", align_corners=False)
+    dy = _rb(torch.randn_like(ur))
+    ur.backward(dy)
+    xg = _dev(x).requires_grad_(True)
+    ug = ops.upsample3d(xg, scale_factor=2, mode="trilinear", align_corners=False)
+    assert ug.dtype == BF
+    _close(ug, ur, "trilinear x2 forward")
+    ug.backward(_dev(dy))
+    _close(xg.grad, xr.grad, "trilinear x2 backward")
+
+
 @pytest.mark.parametrize("scale", [2, 4])
 def test_nearest_upsampling_backward_with_an_integer_scale_bf16(scale):
     """nn.Upsample(scale_factor=S, mode='nearest') backward on bf16 tensors (the S^3 box-sum kernel; AE_model.py:110-120 uses S = 4):

@@ -299,7 +299,12 @@ def test_max_pool3d_ties_pick_first_like_torch():
 UP_CASES = [("nearest", None, 2, None, 16, (5, 6, 7)), ("nearest", None, 4, None, 8, (3, 4, 2)),
             ("nearest", (9, 11, 13), None, None, 4, (4, 5, 6)), ("nearest", (7, 7, 7), None, None, 1, (7, 3, 9)),
             ("trilinear", None, 2, False, 32, (5, 6, 4)), ("trilinear", None, 2, True, 8, (5, 6, 4)),
-            ("trilinear", (7, 9, 11), None, False, 4, (4, 5, 6)), ("trilinear", None, 2, False, 3, (1, 4, 5))]
+            ("trilinear", (7, 9, 11), None, False, 4, (4, 5, 6)), ("trilinear", None, 2, False, 3, (1, 4, 5)),
+            # x2 trilinear marching along D (4 x 16 coarse columns, 16-plane segments): ragged columns in h and w, two segments,
+            # 8 / 4 / 2 / 1 pieces per voxel, a half-empty second channel pass (24 channels), two full passes (64)
+            ("trilinear", None, 2, False, 64, (18, 9, 19)), ("trilinear", None, 2, False, 24, (3, 5, 33)),
+            ("trilinear", None, 2, False, 16, (17, 4, 16)), ("trilinear", None, 2, False, 8, (2, 7, 5)),
+            ("trilinear", None, 2, False, 4, (33, 3, 18))]
 
 
 @pytest.mark.parametrize("mode,size,scale,ac,c,sp", UP_CASES)

@@ -1,4 +1,4 @@
-"""Times trilinear x2 upsample forward/backward through the C ABI:  python tools/upsample_probe.py C D H W [N] [f32|bf16]
+"""Times trilinear x2 upsample forward/backward through the C ABI:  python tools/upsample_probe.py [--lib SO] C D H W [N] [f32|bf16]
 (coarse size D H W; MRI3D_UP_GENERIC=1 selects the generic gather kernels for an A/B)."""
 import os
 import sys
@@ -6,7 +6,12 @@ import sys
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from mri_epilepsy_diagnosis_amd import ops  # noqa: E402
+from mri_epilepsy_diagnosis_amd import _lib, ops  # noqa: E402
+
+if "--lib" in sys.argv:   # a tuning build, e.g. the previous commit as variant "prev"
+    i = sys.argv.index("--lib")
+    _lib.LIB_PATH = os.path.abspath(sys.argv[i + 1])
+    del sys.argv[i:i + 2]
 
 c, d, h, w = (int(a) for a in sys.argv[1:5])
 n = int(sys.argv[5]) if len(sys.argv) > 5 else 2
