@@ -108,6 +108,24 @@ int mri3d_conv3d_fwd_march(const Mri3dConvGeom* g, const void* x, const void* x2
 int mri3d_conv3d_dgrad_march(const Mri3dConvGeom* g, const void* dy, const void* w, void* dx, void* dx2, int32_t split,
                              int32_t dx2_ld, void* workspace, size_t ws_bytes, mri3d_stream_t stream);
 
+/* Conv3d over a nearest-neighbour upsampled input that is never formed (csrc/upconv.hip):
+ *     y = conv3d(upsample_nearest(x, scale_factor = scale), w, bias, stride 1, padding g->p*)
+ * replaces nn.Upsample(scale_factor=4, mode='nearest') followed by the block's first nn.Conv3d in UpBlock
+ * (classification/models/AE_model.py:110-120 with up='upsample'; the last block: Conv3d(8, 1, (3,1,1)) at 160x192x160).
+ * g describes the convolution on the VIRTUAL fine input: di, hi, wi = scale x the extents of the coarse tensor x
+ * (n, di/scale, hi/scale, wi/scale, ci) whose voxel pitch is x_ld; y / dy have pitch y_ld.  dgrad writes the gradient of the
+ * COARSE tensor (each coarse voxel = the sum over its scale^3 fine voxels, fixed summation order).  Served geometries:
+ * mri3d_upconv3d_supported(g, scale) = 1 (scale 2 or 4, stride 1, dilation 1, <= 8 taps, the (ci, co, taps) instances listed in
+ * upconv.hip); everything else returns MRI3D_ENOTSUP and the caller keeps the two separate operators.  wgrad workspace:
+ * mri3d_upconv3d_workspace_bytes. */
+int32_t mri3d_upconv3d_supported(const Mri3dConvGeom* g, int32_t scale);
+size_t mri3d_upconv3d_workspace_bytes(const Mri3dConvGeom* g, int32_t scale);
+int mri3d_upconv3d_fwd(const Mri3dConvGeom* g, int32_t scale, const void* x, const float* w, const float* bias, void* y,
+                       mri3d_stream_t stream);
+int mri3d_upconv3d_dgrad(const Mri3dConvGeom* g, int32_t scale, const void* dy, const float* w, void* dx, mri3d_stream_t stream);
+int mri3d_upconv3d_wgrad(const Mri3dConvGeom* g, int32_t scale, const void* x, const void* dy, float* dw, float* dbias,
+                         void* workspace, size_t ws_bytes, mri3d_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------------
  * BatchNorm3d / InstanceNorm3d fused with the following activation — replaces
  * nn.BatchNorm3d + nn.PReLU (unet.UNet ConvolutionalBlock), nn.BatchNorm3d + LeakyReLU/ReLU

@@ -66,6 +66,11 @@ SIGNATURES = {
     "mri3d_conv3d_march_stats_blocks": (c_int32, [POINTER(ConvGeom)]),
     "mri3d_conv3d_fwd_march": (c_int32, [POINTER(ConvGeom), _P, _P, c_int32, c_int32, _P, _P, _P, _P, _P, c_size_t, _P]),
     "mri3d_conv3d_dgrad_march": (c_int32, [POINTER(ConvGeom), _P, _P, _P, _P, c_int32, c_int32, _P, c_size_t, _P]),
+    "mri3d_upconv3d_supported": (c_int32, [POINTER(ConvGeom), c_int32]),
+    "mri3d_upconv3d_workspace_bytes": (c_size_t, [POINTER(ConvGeom), c_int32]),
+    "mri3d_upconv3d_fwd": (c_int32, [POINTER(ConvGeom), c_int32, _P, _FP, _FP, _P, _P]),
+    "mri3d_upconv3d_dgrad": (c_int32, [POINTER(ConvGeom), c_int32, _P, _FP, _P, _P]),
+    "mri3d_upconv3d_wgrad": (c_int32, [POINTER(ConvGeom), c_int32, _P, _P, _FP, _FP, _P, c_size_t, _P]),
     "mri3d_norm_workspace_bytes": (c_size_t, [POINTER(NormGeom)]),
     "mri3d_norm_stats": (c_int32, [POINTER(NormGeom), _P, _FP, _FP, _FP, _FP, c_float, _P, c_size_t, _P]),
     "mri3d_norm_stats_from_partials": (c_int32, [POINTER(NormGeom), _P, c_int32, _FP, _FP, _FP, _FP, _FP, c_float, _P]),

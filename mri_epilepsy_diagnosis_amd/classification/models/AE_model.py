@@ -85,7 +85,15 @@ class UpBlock(tnn.Module, _InitMixin):
 
     def forward(self, x, shape_before_pool=None, x_before_pool=None):
         mods = [m for _, m in sorted(self.block.items())]
-        x = mods[0](x)  # "1_upsample"
+        up, conv = mods[0], mods[1]   # "1_upsample", "2_convx"
+        if (isinstance(up, mnn.Upsample) and up.mode == "nearest" and up.size is None and isinstance(up.scale_factor, (int, float))
+                and all(shape_before_pool[a] <= int(x.shape[2 + a] * up.scale_factor) for a in range(3))
+                and ops.upsample_conv3d_supported(x, conv.weight, up.scale_factor, conv.stride, conv.padding, conv.dilation)):
+            # the upsampled tensor is never formed (the last block: 8 channels at 160x192x160): the first convolution reads the
+            # coarse tensor through the nearest-neighbour index map (ops.upsample_conv3d)
+            x = ops.upsample_conv3d(x, int(up.scale_factor), conv.weight, conv.bias, conv.padding)
+            return mnn.run_fused(mods[2:], x)
+        x = up(x)
         if any(shape_before_pool[a] > x.shape[2 + a] for a in range(3)):  # odd sizes: nearest resize to the skip size
             x = ops.upsample3d(x, size=tuple(shape_before_pool[:3]), mode="nearest")
         return mnn.run_fused(mods[1:], x)

@@ -1077,6 +1077,87 @@ def upsample3d(x, size=None, scale_factor=None, mode="nearest", align_corners=No
     return _Upsample3dFn.apply(x, out_sz, code, ac, tuple(ratios), out)
 
 
+class _UpConv3dFn(torch.autograd.Function):
+    """conv3d(upsample_nearest(x, scale), w, b, stride 1, padding) without the upsampled tensor (csrc/upconv.hip): the last
+    UpBlock of the autoencoder (AE_model.py:110-120) — see upsample_conv3d."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, scale, padding):
+        _require_device(x)
+        _require_param(weight, bias)
+        L = _lib.lib()
+        x, x_ld = _nd(x)
+        w = weight.contiguous()
+        n, c, d, h, wd = x.shape
+        g = _conv_geom((n, c, d * scale, h * scale, wd * scale), w.shape, (1, 1, 1), padding, (1, 1, 1), x_ld=x_ld, dtype=_dt(x))
+        y = _new((g.n, g.co, g.dout, g.ho, g.wo), x)
+        with _timed(lambda: _conv_tag("fwd", g) + " of nearest x%d" % scale,
+                    lambda: {"flops": _conv_work(g, "fwd")["flops"], "bytes": _esz(x) * (x.numel() + y.numel())}):
+            check(L.mri3d_upconv3d_fwd(ctypes.byref(g), scale, _ptr(x), _ptr(w), _ptr(bias), _ptr(y), _stream()), "upconv3d_fwd")
+        ctx.save_for_backward(x, w)
+        ctx.geom, ctx.scale, ctx.padding = g, scale, padding
+        ctx.has_bias = bias is not None
+        ctx.params = (weight, bias)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        L = _lib.lib()
+        x, w = ctx.saved_tensors
+        g0, scale = ctx.geom, ctx.scale
+        dy, y_ld = _nd(dy)
+        fine = (g0.n, g0.ci, g0.di, g0.hi, g0.wi)
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            gd = _conv_geom(fine, w.shape, (1, 1, 1), ctx.padding, (1, 1, 1), x_ld=g0.ci, y_ld=y_ld, dtype=g0.dtype)
+            dx = _new(tuple(x.shape), x)
+            with _timed(lambda: _conv_tag("dgrad", gd) + " onto nearest x%d" % scale,
+                        lambda: {"flops": _conv_work(gd, "dgrad")["flops"], "bytes": _esz(dy) * (dx.numel() + dy.numel())}):
+                check(L.mri3d_upconv3d_dgrad(ctypes.byref(gd), scale, _ptr(dy), _ptr(w), _ptr(dx), _stream()), "upconv3d_dgrad")
+        if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
+            gw = _conv_geom(fine, w.shape, (1, 1, 1), ctx.padding, (1, 1, 1), x_ld=g0.x_ld, y_ld=y_ld, dtype=g0.dtype)
+            wp, bp = ctx.params
+            want_b = ctx.has_bias and ctx.needs_input_grad[2]
+            dw_out = _sink_take(wp) if ctx.needs_input_grad[1] else None
+            db_out = _sink_take(bp) if want_b else None
+            dw = dw_out if dw_out is not None else torch.empty_like(w, memory_format=torch.contiguous_format)
+            db = (db_out if db_out is not None else torch.empty(gw.co, dtype=w.dtype, device=w.device)) if ctx.has_bias else None
+            ws = _workspace(L.mri3d_upconv3d_workspace_bytes(ctypes.byref(gw), scale), x.device)
+            with _timed(lambda: _conv_tag("wgrad", gw) + " of nearest x%d" % scale,
+                        lambda: {"flops": _conv_work(gw, "wgrad")["flops"], "bytes": _esz(dy) * (x.numel() + dy.numel())}):
+                check(L.mri3d_upconv3d_wgrad(ctypes.byref(gw), scale, _ptr(x), _ptr(dy), _ptr(dw), _ptr(db), _ptr(ws), ws.numel(),
+                                             _stream()), "upconv3d_wgrad")
+            dw = _sink_done(wp, dw, dw_out) if ctx.needs_input_grad[1] else None
+            db = _sink_done(bp, db, db_out) if want_b else None
+        return dx, dw, db, None, None
+
+
+def upsample_conv3d_supported(x, weight, scale, stride=1, padding=0, dilation=1):
+    """True when conv3d(upsample_nearest(x, scale), weight) is served without the upsampled tensor (mri3d_upconv3d_supported)."""
+    if not (isinstance(scale, int) or (isinstance(scale, float) and float(scale).is_integer())):
+        return False
+    scale = int(scale)
+    if _triple(stride) != (1, 1, 1) or _triple(dilation) != (1, 1, 1) or x.dim() != 5 or not x.is_cuda:
+        return False
+    n, c, d, h, w = x.shape
+    if weight.shape[1] != c:
+        return False
+    try:
+        g = _conv_geom((n, c, d * scale, h * scale, w * scale), tuple(weight.shape), (1, 1, 1), _triple(padding), (1, 1, 1),
+                       x_ld=_pitch_of(x) or c, dtype=_dt(x))
+    except RuntimeError:
+        return False
+    return bool(_lib.lib().mri3d_upconv3d_supported(ctypes.byref(g), scale))
+
+
+def upsample_conv3d(x, scale, weight, bias=None, padding=0):
+    """conv3d(F.interpolate(x, scale_factor=scale, mode='nearest'), weight, bias, stride=1, padding=padding) — the head of the
+    reference's UpBlock (AE_model.py:110-120) — through the fused operator where it is served, else through the two operators."""
+    if upsample_conv3d_supported(x, weight, scale, 1, padding, 1):
+        return _UpConv3dFn.apply(x, weight, bias, int(scale), _triple(padding))
+    return conv3d(upsample3d(x, scale_factor=scale, mode="nearest"), weight, bias, stride=1, padding=padding)
+
+
 # ----------------------------------------------------------------------------------------------- loss
 
 

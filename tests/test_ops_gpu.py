@@ -322,6 +322,57 @@ def test_upsample3d(mode, size, scale, ac, c, sp):
     assert_close(to_ncdhw(xd.grad), xr.grad, rel=1e-5, what="dx")
 
 
+# conv3d over a nearest-upsampled input that is never formed (csrc/upconv.hip; UpBlock of AE_model.py:110-120): the shipped last
+# block (8 -> 1, (3,1,1), scale 4), the other two axes, scale 2, a pointwise head, six taps with padding 2, and a shape the fused
+# operator does not serve (16 -> 8: falls back to the two operators)
+UPCONV_CASES = [(8, 1, (3, 1, 1), (1, 0, 0), 4, (3, 4, 5)), (8, 1, (1, 3, 1), (0, 1, 0), 4, (2, 3, 4)), (4, 2, (1, 1, 3), (0, 0, 1), 2, (5, 6, 7)),
+                (8, 8, (1, 1, 1), (0, 0, 0), 4, (2, 2, 3)), (8, 1, (6, 1, 1), (2, 0, 0), 2, (6, 3, 4)), (16, 8, (3, 1, 1), (1, 0, 0), 4, (2, 3, 2)),
+                (8, 2, (3, 1, 1), (0, 0, 0), 4, (3, 2, 2))]
+
+
+@pytest.mark.parametrize("ci,co,k,pad,scale,sp", UPCONV_CASES)
+def test_upsample_conv3d_equals_nearest_upsampling_then_conv(ci, co, k, pad, scale, sp):
+    x = seeded_randn(1, (2, ci, *sp))
+    w = seeded_randn(2, (co, ci, *k)) * 0.3
+    b = seeded_randn(3, (co,))
+    xr, wr, br = x.clone().requires_grad_(True), w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    yr = F.conv3d(F.interpolate(xr, scale_factor=scale, mode="nearest"), wr, br, padding=pad)
+    gy = seeded_randn(4, tuple(yr.shape))
+    yr.backward(gy)
+    xd = _dev(x)
+    wd, bd = w.to(DEV).requires_grad_(True), b.to(DEV).requires_grad_(True)
+    served = ops.upsample_conv3d_supported(xd, wd, scale, 1, pad, 1)
+    assert served == ((ci, co) != (16, 8))
+    yd = ops.upsample_conv3d(xd, scale, wd, bd, padding=pad)
+    assert tuple(yd.shape) == tuple(yr.shape)
+    yd.backward(_dev(gy, False))
+    assert_close(to_ncdhw(yd), yr, rel=1e-5, what="y")
+    assert_close(to_ncdhw(xd.grad), xr.grad, rel=1e-5, what="dx (coarse)")
+    assert_close(wd.grad.cpu(), wr.grad, rel=1e-5, what="dw")
+    assert_close(bd.grad.cpu(), br.grad, rel=1e-5, what="db")
+
+
+def test_upsample_conv3d_is_deterministic_and_matches_the_two_operators_bf16():
+    x = seeded_randn(5, (2, 8, 4, 5, 6)).to(torch.bfloat16)
+    w = (seeded_randn(6, (1, 8, 3, 1, 1)) * 0.3).to(DEV).requires_grad_(True)
+    b = seeded_randn(7, (1,)).to(DEV).requires_grad_(True)
+    res = []
+    for fused in (True, True, False):
+        xd = x.to(DEV).contiguous(memory_format=torch.channels_last_3d).requires_grad_(True)
+        w.grad = b.grad = None
+        if fused:
+            y = ops.upsample_conv3d(xd, 4, w, b, padding=(1, 0, 0))
+        else:
+            y = ops.conv3d(ops.upsample3d(xd, scale_factor=4, mode="nearest"), w, b, padding=(1, 0, 0))
+        g = torch.Generator(device=DEV).manual_seed(9)
+        y.backward(torch.randn(y.shape, device=DEV, generator=g).to(y.dtype).contiguous(memory_format=torch.channels_last_3d))
+        res.append((y.detach().float(), xd.grad.float(), w.grad.clone(), b.grad.clone()))
+    for a, c in zip(res[0], res[1]):
+        assert torch.equal(a, c)                      # run to run: bit for bit
+    for a, c, tol in zip(res[0], res[2], (2e-2, 3e-2, 1e-3, 1e-3)):   # against the two operators: bf16 storage of the 8-channel tensors
+        assert float((a - c).abs().max()) <= tol * float(c.abs().max() + 1e-6)
+
+
 # ---------------------------------------------------------------------------------------------- loss / mask / plumbing
 @pytest.mark.parametrize("n,c,ct,sp", [(1, 2, 1, (8, 8, 8)), (2, 2, 1, (9, 7, 5)), (2, 3, 3, (6, 6, 6)), (1, 2, 2, (4, 4, 4))])
 def test_softmax_dice_loss(n, c, ct, sp):
