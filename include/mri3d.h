@@ -126,6 +126,18 @@ int mri3d_upconv3d_dgrad(const Mri3dConvGeom* g, int32_t scale, const void* dy, 
 int mri3d_upconv3d_wgrad(const Mri3dConvGeom* g, int32_t scale, const void* x, const void* dy, float* dw, float* dbias,
                          void* workspace, size_t ws_bytes, mri3d_stream_t stream);
 
+/* The first two convolutions of the autoencoder's first DownBlock (classification/models/AE_model.py:45-53, shipped kwargs conv_k=6,
+ * conv_s=2, conv_pad=2): first = Conv3d(1, 8, (6,1,1), stride (s,1,1), padding (p,0,0)) on the input volume, second =
+ * Conv3d(8, 8, (1,k,1), stride (1,s,1), padding (0,p,0)) on its output (csrc/sepconv.hip).  mri3d_convpair_wgrad_first computes the
+ * FIRST convolution's weight / bias gradient from the gradient dy2 of the SECOND convolution's output (pitch second->y_ld), the
+ * second convolution's weight w2 (torch layout) and the input x (pitch first->x_ld): what mri3d_conv3d_dgrad(second) followed by
+ * mri3d_conv3d_wgrad(first) compute, without the intermediate gradient tensor.  dw1: (8, 1, 6, 1, 1); dbias1: (8) or NULL.
+ * Served pairs: mri3d_convpair_supported = 1 (second's input must be first's output); else MRI3D_ENOTSUP. */
+int32_t mri3d_convpair_supported(const Mri3dConvGeom* first, const Mri3dConvGeom* second);
+size_t mri3d_convpair_workspace_bytes(const Mri3dConvGeom* first, const Mri3dConvGeom* second);
+int mri3d_convpair_wgrad_first(const Mri3dConvGeom* first, const Mri3dConvGeom* second, const void* x, const void* dy2, const float* w2,
+                               float* dw1, float* dbias1, void* workspace, size_t ws_bytes, mri3d_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------------
  * BatchNorm3d / InstanceNorm3d fused with the following activation — replaces
  * nn.BatchNorm3d + nn.PReLU (unet.UNet ConvolutionalBlock), nn.BatchNorm3d + LeakyReLU/ReLU

@@ -71,6 +71,9 @@ SIGNATURES = {
     "mri3d_upconv3d_fwd": (c_int32, [POINTER(ConvGeom), c_int32, _P, _FP, _FP, _P, _P]),
     "mri3d_upconv3d_dgrad": (c_int32, [POINTER(ConvGeom), c_int32, _P, _FP, _P, _P]),
     "mri3d_upconv3d_wgrad": (c_int32, [POINTER(ConvGeom), c_int32, _P, _P, _FP, _FP, _P, c_size_t, _P]),
+    "mri3d_convpair_supported": (c_int32, [POINTER(ConvGeom), POINTER(ConvGeom)]),
+    "mri3d_convpair_workspace_bytes": (c_size_t, [POINTER(ConvGeom), POINTER(ConvGeom)]),
+    "mri3d_convpair_wgrad_first": (c_int32, [POINTER(ConvGeom), POINTER(ConvGeom), _P, _P, _FP, _FP, _FP, _P, c_size_t, _P]),
     "mri3d_norm_workspace_bytes": (c_size_t, [POINTER(NormGeom)]),
     "mri3d_norm_stats": (c_int32, [POINTER(NormGeom), _P, _FP, _FP, _FP, _FP, c_float, _P, c_size_t, _P]),
     "mri3d_norm_stats_from_partials": (c_int32, [POINTER(NormGeom), _P, c_int32, _FP, _FP, _FP, _FP, _FP, c_float, _P]),

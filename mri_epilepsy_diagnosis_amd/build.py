@@ -12,7 +12,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(HERE, "csrc", "build")
 LIB = os.path.join(HERE, "libmri3d_hip.so")
-SOURCES = ["api.hip", "conv_generic.hip", "conv_mfma.hip", "conv_march.hip", "conv_pointwise.hip", "upconv.hip", "norm.hip", "resample.hip", "loss.hip", "elementwise.hip", "preprocess.hip", "surface.hip", "patches.hip"]
+SOURCES = ["api.hip", "conv_generic.hip", "conv_mfma.hip", "conv_march.hip", "conv_pointwise.hip", "upconv.hip", "sepconv.hip", "norm.hip", "resample.hip", "loss.hip", "elementwise.hip", "preprocess.hip", "surface.hip", "patches.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function"]
 # per-file additions.  conv_march.hip keeps its accumulators in a[0:95] BY NAME (inline asm): hipcc must never park a VGPR in an

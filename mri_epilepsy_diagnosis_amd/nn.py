@@ -170,6 +170,13 @@ def run_fused(modules, x):
     while i < len(mods):
         m = mods[i]
         five_d = torch.is_tensor(x) and x.dim() == 5
+        if (five_d and i == 0 and isinstance(m, Conv3d) and len(mods) > 2 and isinstance(mods[1], Conv3d) and isinstance(mods[2], Conv3d)
+                and ops.conv3d_pair_supported(x, m, mods[1])):
+            # the head of the autoencoder's first DownBlock on the network input: the gradient of the (k,1,1) convolution's output is
+            # never formed (ops.conv3d_pair)
+            x = ops.conv3d_pair(x, m, mods[1])
+            i += 2
+            continue
         if five_d and isinstance(m, Conv3d) and i + 1 < len(mods) and isinstance(mods[i + 1], tnn.BatchNorm3d):
             nxt2 = mods[i + 2] if i + 2 < len(mods) else None
             if isinstance(nxt2, _ACTS):

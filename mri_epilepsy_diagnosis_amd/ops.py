@@ -614,6 +614,91 @@ def conv3d(x, weight, bias=None, stride=1, padding=0, dilation=1, bn_stats=False
     return y
 
 
+class _ConvPairFn(torch.autograd.Function):
+    """y = conv3d(conv3d(x, w1, b1, stride s1, padding p1), w2, b2, stride s2, padding p2) for the head of the autoencoder's first
+    DownBlock (AE_model.py:45-53: (6,1,1) on the one-channel input, then (1,k,1)), x a network input (no gradient).  Forward = the two
+    convolutions; backward never forms the gradient of the intermediate tensor: w1's gradient comes from dy, w2 and x
+    (mri3d_convpair_wgrad_first, csrc/sepconv.hip)."""
+
+    @staticmethod
+    def forward(ctx, x, w1, b1, w2, b2, conv1, conv2):
+        _require_device(x)
+        _require_param(w1, b1)
+        _require_param(w2, b2)
+        x, x_ld = _nd(x)
+        w1c, w2c = w1.contiguous(), w2.contiguous()
+        g1 = _conv_geom(x.shape, w1c.shape, conv1[0], conv1[1], (1, 1, 1), x_ld=x_ld, dtype=_dt(x))
+        a1 = _conv_fwd(g1, x, w1c, b1)
+        g2 = _conv_geom(a1.shape, w2c.shape, conv2[0], conv2[1], (1, 1, 1), dtype=_dt(x))
+        y = _conv_fwd(g2, a1, w2c, b2)
+        ctx.save_for_backward(x, a1, w2c)
+        ctx.geoms = (g1, g2)
+        ctx.params = (w1, b1, w2, b2)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        L = _lib.lib()
+        x, a1, w2c = ctx.saved_tensors
+        g1, g2 = ctx.geoms
+        w1, b1, w2, b2 = ctx.params
+        dy, y_ld = _nd(dy)
+        stride2, pad2 = (g2.sd, g2.sh, g2.sw), (g2.pd, g2.ph, g2.pw)
+        gw2 = _conv_geom(a1.shape, w2c.shape, stride2, pad2, (1, 1, 1), y_ld=y_ld, dtype=g2.dtype)
+        # second convolution: the ordinary weight gradient
+        need_w2, need_b2 = ctx.needs_input_grad[3], b2 is not None and ctx.needs_input_grad[4]
+        dw2 = db2 = None
+        if need_w2 or need_b2:
+            dw2_out = _sink_take(w2) if need_w2 else None
+            db2_out = _sink_take(b2) if need_b2 else None
+            dw2, db2 = _conv_wgrad(gw2, a1, dy, w2c, b2 is not None, dw2_out, db2_out)
+            dw2 = _sink_done(w2, dw2, dw2_out) if need_w2 else None
+            db2 = _sink_done(b2, db2, db2_out) if need_b2 else None
+        # first convolution: from dy, w2 and x, without the gradient of a1
+        need_w1, need_b1 = ctx.needs_input_grad[1], b1 is not None and ctx.needs_input_grad[2]
+        dw1 = db1 = None
+        if need_w1 or need_b1:
+            dw1_out = _sink_take(w1) if need_w1 else None
+            db1_out = _sink_take(b1) if need_b1 else None
+            dw1 = dw1_out if dw1_out is not None else torch.empty_like(w1, memory_format=torch.contiguous_format)
+            db1 = (db1_out if db1_out is not None else torch.empty(g1.co, dtype=w1.dtype, device=w1.device)) if b1 is not None else None
+            ws = _workspace(L.mri3d_convpair_workspace_bytes(ctypes.byref(g1), ctypes.byref(gw2)), x.device)
+            with _timed(lambda: _conv_tag("wgrad", g1) + " through " + _conv_tag("dgrad", gw2),
+                        lambda: {"flops": _conv_work(g1, "wgrad")["flops"] + _conv_work(gw2, "dgrad")["flops"],
+                                 "bytes": _esz(dy) * (x.numel() + dy.numel())}):
+                check(L.mri3d_convpair_wgrad_first(ctypes.byref(g1), ctypes.byref(gw2), _ptr(x), _ptr(dy), _ptr(w2c), _ptr(dw1), _ptr(db1),
+                                                   _ptr(ws), ws.numel(), _stream()), "convpair_wgrad_first")
+            dw1 = _sink_done(w1, dw1, dw1_out) if need_w1 else None
+            db1 = _sink_done(b1, db1, db1_out) if need_b1 else None
+        return None, dw1, db1, dw2, db2, None, None
+
+
+def conv3d_pair_supported(x, conv1, conv2):
+    """True when conv2(conv1(x)) is served by _ConvPairFn: x needs no gradient and mri3d_convpair_supported takes the pair.
+    conv1 / conv2: modules with weight, bias, stride, padding, dilation (nn.Conv3d)."""
+    if not (torch.is_tensor(x) and x.dim() == 5 and x.is_cuda) or x.requires_grad or _autocast_dtype is not None:
+        return False
+    if _triple(conv1.dilation) != (1, 1, 1) or _triple(conv2.dilation) != (1, 1, 1) or conv1.weight.shape[1] != x.shape[1]:
+        return False
+    try:
+        g1 = _conv_geom(tuple(x.shape), tuple(conv1.weight.shape), _triple(conv1.stride), _triple(conv1.padding), (1, 1, 1),
+                        x_ld=_pitch_of(x) or x.shape[1], dtype=_dt(x))
+        g2 = _conv_geom((g1.n, g1.co, g1.dout, g1.ho, g1.wo), tuple(conv2.weight.shape), _triple(conv2.stride), _triple(conv2.padding),
+                        (1, 1, 1), dtype=_dt(x))
+    except RuntimeError:
+        return False
+    return bool(_lib.lib().mri3d_convpair_supported(ctypes.byref(g1), ctypes.byref(g2)))
+
+
+def conv3d_pair(x, conv1, conv2):
+    """conv2(conv1(x)) for two nn.Conv3d modules; the fused backward where conv3d_pair_supported, else the two operators."""
+    if conv3d_pair_supported(x, conv1, conv2):
+        return _ConvPairFn.apply(x, conv1.weight, conv1.bias, conv2.weight, conv2.bias,
+                                 (_triple(conv1.stride), _triple(conv1.padding)), (_triple(conv2.stride), _triple(conv2.padding)))
+    y = conv3d(x, conv1.weight, conv1.bias, conv1.stride, conv1.padding, conv1.dilation)
+    return conv3d(y, conv2.weight, conv2.bias, conv2.stride, conv2.padding, conv2.dilation)
+
+
 def _channel_sum(t):
     """sum over (N,D,H,W) per channel with the norm-statistics kernel (mean * count)."""
     L = _lib.lib()

@@ -373,6 +373,34 @@ def test_upsample_conv3d_is_deterministic_and_matches_the_two_operators_bf16():
         assert float((a - c).abs().max()) <= tol * float(c.abs().max() + 1e-6)
 
 
+# the head of the autoencoder's first DownBlock (AE_model.py:45-53): Conv3d(1, 8, (6,1,1), s (2,1,1), p (2,0,0)) then Conv3d(8, 8, (1,k,1),
+# s (1,s,1), p (0,p,0)) — the first convolution's weight gradient without the gradient of its output (csrc/sepconv.hip); odd extents,
+# a width that is not a multiple of 64, stride 1 and 3 for the second convolution, k = 3
+@pytest.mark.parametrize("sp,k2,s2,p2", [((12, 10, 9), 6, 2, 2), ((7, 9, 70), 6, 2, 2), ((8, 6, 5), 3, 1, 1), ((6, 11, 33), 6, 3, 2)])
+def test_conv3d_pair_gradients_equal_the_two_convolutions(sp, k2, s2, p2):
+    class Conv:   # what ops.conv3d_pair reads of an nn.Conv3d
+        def __init__(self, w, b, stride, padding):
+            self.weight, self.bias, self.stride, self.padding, self.dilation = w, b, stride, padding, (1, 1, 1)
+
+    x = seeded_randn(1, (2, 1, *sp))
+    w1, b1 = seeded_randn(2, (8, 1, 6, 1, 1)) * 0.4, seeded_randn(3, (8,))
+    w2, b2 = seeded_randn(4, (8, 8, 1, k2, 1)) * 0.2, seeded_randn(5, (8,))
+    ref = [t.clone().requires_grad_(True) for t in (w1, b1, w2, b2)]
+    yr = F.conv3d(F.conv3d(x, ref[0], ref[1], stride=(2, 1, 1), padding=(2, 0, 0)), ref[2], ref[3], stride=(1, s2, 1), padding=(0, p2, 0))
+    gy = seeded_randn(6, tuple(yr.shape))
+    yr.backward(gy)
+    dev = [t.to(DEV).requires_grad_(True) for t in (w1, b1, w2, b2)]
+    c1, c2 = Conv(dev[0], dev[1], (2, 1, 1), (2, 0, 0)), Conv(dev[2], dev[3], (1, s2, 1), (0, p2, 0))
+    xd = _dev(x, False)
+    assert ops.conv3d_pair_supported(xd, c1, c2)
+    assert not ops.conv3d_pair_supported(_dev(x, True), c1, c2)        # an input that needs its gradient keeps the two operators
+    yd = ops.conv3d_pair(xd, c1, c2)
+    yd.backward(_dev(gy, False))
+    assert_close(to_ncdhw(yd), yr, rel=1e-5, what="y")
+    for got, want, what in zip(dev, ref, ("dw1", "db1", "dw2", "db2")):
+        assert_close(got.grad.cpu(), want.grad, rel=2e-5, what=what)
+
+
 # ---------------------------------------------------------------------------------------------- loss / mask / plumbing
 @pytest.mark.parametrize("n,c,ct,sp", [(1, 2, 1, (8, 8, 8)), (2, 2, 1, (9, 7, 5)), (2, 3, 3, (6, 6, 6)), (1, 2, 2, (4, 4, 4))])
 def test_softmax_dice_loss(n, c, ct, sp):
