@@ -1936,7 +1936,10 @@ conv_mfma_wgrad_bf16_kernel(const bf16_t* __restrict__ x, const bf16_t* __restri
 // fabric: with the MFMAs compiled out the 48 -> 16 layer still takes 0.415 ms (its three ci-tile workgroups each fetch dY: PMC
 // 2.0x the algorithmic bytes, 5 TB/s), with the DMA compiled out 0.280 ms; with every workgroup on one L2-resident column the
 // DMA alone runs at 14 TB/s.  (Workgroups of one task's ci-tiles share an XCD — tools/microbench/xcc_probe.hip — yet run in lock
-// step and miss together; a start skew does not survive, the follower catches up.)
+// step and miss together; a start skew does not survive, the follower catches up.  One workgroup per CU taking all three ci-tiles
+// against a single staging of dY — scatter form, dY in a five-plane ring, X triple-buffered, 138 KB of LDS — was built and is
+// parity-green but slower: 0.72 ms with six waves of four rows (one or two waves per SIMD expose every fragment read and the
+// step barrier), and twelve waves of two rows do not fit 170 registers: hipcc spills inside the MFMA loop.)
 constexpr int MTH = 8, MXR = MTH + 2;                 // output rows / X rows per plane
 constexpr int kMarchSeg = 40;                         // planes per task at most (4 fill steps per task); shorter for small volumes
 constexpr int TXROW = BTW * 32;                       //  1 024 B  one X row: 32 voxels x 16 channels
