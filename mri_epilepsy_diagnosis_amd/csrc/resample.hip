@@ -655,7 +655,10 @@ upsample2x_bwd_march_kernel(Mri3dUpGeom g, const T* __restrict__ dy, T* __restri
         T* dxo = dx + (((int64_t)n * g.di * g.hi + ih) * g.wi + iw) * g.x_ld + c0 + 4 * q;
         const int64_t xplane = (int64_t)g.hi * g.wi * g.x_ld;
         // (A second register set — plane f+2 in flight while plane f+1 waits for its LDS write, the step barrier ordering LDS only —
-        // measured SLOWER: 0.369 -> 0.393 ms fp32, 0.225 -> 0.31 ms bf16 on the 32-channel level; the step is not one exposed round trip.)
+        // measured SLOWER: 0.369 -> 0.393 ms fp32, 0.225 -> 0.31 ms bf16 on the 32-channel level; the step is not one exposed round trip.
+        // So did the order turned around — lanes own fine positions and apply the D taps to whole-line loads in registers, one LDS
+        // pass and one 4 x 4 fold per COARSE plane, 32 channels per pass: parity-green, 0.353 ms fp32 and 0.615 ms bf16 at 256
+        // registers per lane.)
         for (int f = f0; f <= f1; ++f) {
             if (f < f1) fetch(f + 1);
             // in-plane 4x4 taps of this lane's coarse (h, w): rows 2*ihl .. 2*ihl+3, columns 2*iwl .. 2*iwl+3 of the tile
