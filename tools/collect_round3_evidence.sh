@@ -17,6 +17,8 @@ cp $O/conv_48_16/conv_48_16_kernel_stats.csv $P/r03_final_rocprofv3_kernel_stats
 cp $O/march_ab_march_bf16.txt $P/r03_march_ab_march_bf16.txt
 cp $O/march_ab_tiled_bf16.txt $P/r03_march_ab_tiled_bf16.txt
 cp $O/syncbn_cost.txt $P/r03_syncbn_cost.txt
+cp $O/cfg3_autoencoder_optable.txt $P/r03_final_cfg3_optables.txt
+cp gpurun_out/pmc_r03f_bf16_wgrad_16_16/summary.txt $P/r03_final_pmc_wgrad_bf16_16_16_summary.txt
 for tag in f32_48_16 bf16_48_16 bf16_16_16; do
   cp gpurun_out/pmc_r03f_${tag}/summary.json $P/r03_final_pmc_conv_${tag}_summary.json
   cp gpurun_out/pmc_r03f_${tag}/summary.txt $P/r03_final_pmc_conv_${tag}_summary.txt

@@ -25,5 +25,8 @@ python3 bench.py --dtype bf16 > $O/final_bench_bf16.json 2> $O/final_bench_bf16_
 python3 tools/march_bench.py --mode march --dtype bf16 2>&1 | grep -v amdgpu.ids > $O/march_ab_march_bf16.txt || exit 1
 python3 tools/march_bench.py --lib mri_epilepsy_diagnosis_amd/libmri3d_hip_nomarch.so --mode auto --dtype bf16 2>&1 | grep -v amdgpu.ids > $O/march_ab_tiled_bf16.txt || exit 1
 python3 tools/syncbn_cost.py 2>&1 | grep -v amdgpu.ids > $O/syncbn_cost.txt || exit 1
+TOP=70 python3 tools/model_bench.py cfg3ae 2>&1 | grep -v amdgpu.ids > $O/cfg3_autoencoder_optable.txt || exit 1
+TOP=40 python3 tools/model_bench.py cfg3 2>&1 | grep -v amdgpu.ids >> $O/cfg3_autoencoder_optable.txt || exit 1
+bash tools/pmc_conv.sh r03f_bf16_wgrad_16_16 16 16 160 192 160 2 bf16 "wgrad" || exit 1
 for m in cfg4 m3d m3d_graph cfg3ae_graph cfg3_graph cfg5; do TOP=24 python3 tools/model_bench.py $m 2>&1 | grep -v amdgpu.ids >> $O/final_model_bench.txt || exit 1; done
 cut -c1-300 $O/final_bench_f32.json; cut -c1-300 $O/final_bench_bf16.json; cat $O/syncbn_cost.txt
