@@ -1168,25 +1168,26 @@ constexpr int kC1C1Blocks = 1024;
 constexpr int kC1TBlocks = 1024;
 
 // sign = +1: y[o] = b + sum_t w[t] x[o - p + k_t d]   (forward);   sign = -1: dx[i] = sum_t w[t] dy[i + p - k_t d]   (data gradient)
+template <int NT>   // tap slots: 3 (the autoencoder's (3,1,1) / (1,3,1) / (1,1,3) filters) or kSmTaps
 __global__ void __launch_bounds__(256)
 conv_c1_taps_kernel(Mri3dConvGeom g, const float* __restrict__ src, const float* __restrict__ w, const float* __restrict__ bias,
                     float* __restrict__ dst, int sign, int sD, int sH, int sW, int oD, int oH, int oW) {
     const int taps = g.kd * g.kh * g.kw;
-    const int W4 = oW >> 2;
-    const int64_t rows = (int64_t)g.n * oD * oH;
+    const unsigned W4 = (unsigned)oW >> 2;
+    const unsigned nitems = (unsigned)g.n * oD * oH * W4;   // < 2^31 (c1_taps_ok): 32-bit index arithmetic per item
     const float b0 = bias != nullptr ? bias[0] : 0.f;
-    for (int64_t item = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; item < rows * W4; item += (int64_t)gridDim.x * blockDim.x) {
-        const int q = (int)(item % W4);
-        int64_t r = item / W4;
-        const int oh = (int)(r % oH);
-        r /= oH;
-        const int od = (int)(r % oD), n = (int)(r / oD);
-        const int ow = 4 * q;
+    for (unsigned item = blockIdx.x * blockDim.x + threadIdx.x; item < nitems; item += gridDim.x * blockDim.x) {
+        const unsigned q = item % W4;
+        unsigned r = item / W4;
+        const int oh = (int)(r % (unsigned)oH);
+        r /= (unsigned)oH;
+        const int od = (int)(r % (unsigned)oD), n = (int)(r / (unsigned)oD);
+        const int ow = 4 * (int)q;
         const float* sn = src + (int64_t)n * sD * sH * sW;
-        float4 xv[kSmTaps];
-        unsigned vm[kSmTaps];
+        float4 xv[NT];
+        unsigned vm[NT];
 #pragma unroll
-        for (int t = 0; t < kSmTaps; ++t) {
+        for (int t = 0; t < NT; ++t) {
             const int tt = t < taps ? t : 0;
             const int kw = tt % g.kw, kh = (tt / g.kw) % g.kh, kd = tt / (g.kw * g.kh);
             const int sd_ = od + sign * (kd * g.dd - g.pd), sh_ = oh + sign * (kh * g.dh - g.ph), sw_ = ow + sign * (kw * g.dw - g.pw);
@@ -1207,7 +1208,7 @@ conv_c1_taps_kernel(Mri3dConvGeom g, const float* __restrict__ src, const float*
         }
         float4 acc = make_float4(b0, b0, b0, b0);
 #pragma unroll
-        for (int t = 0; t < kSmTaps; ++t) {
+        for (int t = 0; t < NT; ++t) {
             if (t < taps) {
                 const float wt = w[t];
                 acc.x = fmaf(xv[t].x, wt, acc.x);
@@ -1221,28 +1222,29 @@ conv_c1_taps_kernel(Mri3dConvGeom g, const float* __restrict__ src, const float*
 }
 
 // part[b][t] = sum over the workgroup's voxels of x[o - p + k_t d] * dy[o];  bias_part[b] = sum dy
+template <int NT>
 __global__ void __launch_bounds__(256)
 conv_c1_taps_wgrad_kernel(Mri3dConvGeom g, const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ part,
                           float* __restrict__ bias_part) {
-    __shared__ double red[4][kSmTaps + 1];
+    __shared__ double red[4][NT + 1];
     const int taps = g.kd * g.kh * g.kw;
-    const int W4 = g.wo >> 2;
-    const int64_t rows = (int64_t)g.n * g.dout * g.ho;
-    float acc[kSmTaps + 1];
+    const unsigned W4 = (unsigned)g.wo >> 2;
+    const unsigned nitems = (unsigned)g.n * g.dout * g.ho * W4;   // < 2^31 (c1_taps_ok)
+    float acc[NT + 1];
 #pragma unroll
-    for (int t = 0; t <= kSmTaps; ++t) acc[t] = 0.f;
-    for (int64_t item = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; item < rows * W4; item += (int64_t)gridDim.x * blockDim.x) {
-        const int q = (int)(item % W4);
-        int64_t r = item / W4;
-        const int oh = (int)(r % g.ho);
-        r /= g.ho;
-        const int od = (int)(r % g.dout), n = (int)(r / g.dout);
-        const int ow = 4 * q;
+    for (int t = 0; t <= NT; ++t) acc[t] = 0.f;
+    for (unsigned item = blockIdx.x * blockDim.x + threadIdx.x; item < nitems; item += gridDim.x * blockDim.x) {
+        const unsigned q = item % W4;
+        unsigned r = item / W4;
+        const int oh = (int)(r % (unsigned)g.ho);
+        r /= (unsigned)g.ho;
+        const int od = (int)(r % (unsigned)g.dout), n = (int)(r / (unsigned)g.dout);
+        const int ow = 4 * (int)q;
         const float4 gv = *reinterpret_cast<const float4*>(dy + (((int64_t)n * g.dout + od) * g.ho + oh) * g.wo + ow);
-        acc[kSmTaps] += (gv.x + gv.y) + (gv.z + gv.w);
+        acc[NT] += (gv.x + gv.y) + (gv.z + gv.w);
         const float* xn = x + (int64_t)n * g.di * g.hi * g.wi;
 #pragma unroll
-        for (int t = 0; t < kSmTaps; ++t) {
+        for (int t = 0; t < NT; ++t) {
             const int tt = t < taps ? t : 0;
             const int kw = tt % g.kw, kh = (tt / g.kw) % g.kh, kd = tt / (g.kw * g.kh);
             const int id = od - g.pd + kd * g.dd, ih = oh - g.ph + kh * g.dh, iw = ow - g.pw + kw * g.dw;
@@ -1263,23 +1265,24 @@ conv_c1_taps_wgrad_kernel(Mri3dConvGeom g, const float* __restrict__ x, const fl
     // wave sums (fixed butterfly), then the four waves in double through LDS
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
 #pragma unroll
-    for (int t = 0; t <= kSmTaps; ++t) {
+    for (int t = 0; t <= NT; ++t) {
         float v = acc[t];
 #pragma unroll
         for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
         if (lane == 0) red[wv][t] = (double)v;
     }
     __syncthreads();
-    if (threadIdx.x <= kSmTaps) {
+    if (threadIdx.x <= NT) {
         const double sdbl = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
         if ((int)threadIdx.x < taps) part[(size_t)blockIdx.x * taps + threadIdx.x] = (float)sdbl;
-        if (threadIdx.x == kSmTaps && bias_part != nullptr) bias_part[blockIdx.x] = (float)sdbl;
+        if (threadIdx.x == NT && bias_part != nullptr) bias_part[blockIdx.x] = (float)sdbl;
     }
 }
 
 static bool c1_taps_ok(const Mri3dConvGeom& g) {
     return g.dtype == MRI3D_F32 && g.ci == 1 && g.co == 1 && g.kd * g.kh * g.kw <= kSmTaps && g.sd == 1 && g.sh == 1 && g.sw == 1 &&
-           g.x_ld == 1 && g.y_ld == 1 && g.wo % 4 == 0 && g.wi % 4 == 0 && !(g.kd == 3 && g.kh == 3 && g.kw == 3);
+           g.x_ld == 1 && g.y_ld == 1 && g.wo % 4 == 0 && g.wi % 4 == 0 && !(g.kd == 3 && g.kh == 3 && g.kw == 3) &&
+           (int64_t)g.n * g.dout * g.ho * g.wo < 0x7fffffffLL && (int64_t)g.n * g.di * g.hi * g.wi < 0x7fffffffLL;
 }
 
 static bool c1c1_ok(const Mri3dConvGeom& g) {
@@ -1457,8 +1460,12 @@ int conv_generic_fwd(const Mri3dConvGeom& g, const void* x, const float* w, cons
     if (c1_taps_ok(g) && aligned16(y)) {
         const int64_t items = (int64_t)g.n * g.dout * g.ho * (g.wo / 4);
         const int grid = (int)std::max<int64_t>(1, std::min<int64_t>(cdiv64(items, 256), 8192));
-        hipLaunchKernelGGL(conv_c1_taps_kernel, dim3(grid), dim3(256), 0, s, g, (const float*)x, w, bias, (float*)y, 1, g.di, g.hi,
-                           g.wi, g.dout, g.ho, g.wo);
+        if (g.kd * g.kh * g.kw <= 3)
+            hipLaunchKernelGGL(conv_c1_taps_kernel<3>, dim3(grid), dim3(256), 0, s, g, (const float*)x, w, bias, (float*)y, 1, g.di, g.hi,
+                               g.wi, g.dout, g.ho, g.wo);
+        else
+            hipLaunchKernelGGL(conv_c1_taps_kernel<kSmTaps>, dim3(grid), dim3(256), 0, s, g, (const float*)x, w, bias, (float*)y, 1, g.di,
+                               g.hi, g.wi, g.dout, g.ho, g.wo);
         return check_launch("conv3d_fwd(1->1 taps)");
     }
     if (cin1_ok(g) && aligned_vec4(g.dtype, y)) {
@@ -1723,7 +1730,11 @@ int conv_generic_dgrad(const Mri3dConvGeom& g, const void* dy, const float* w, c
     if (c1_taps_ok(g) && aligned16(dx)) {
         const int64_t items = (int64_t)g.n * g.di * g.hi * (g.wi / 4);
         const int grid = (int)std::max<int64_t>(1, std::min<int64_t>(cdiv64(items, 256), 8192));
-        hipLaunchKernelGGL(conv_c1_taps_kernel, dim3(grid), dim3(256), 0, s, g, (const float*)dy, w, bias, (float*)dx, -1, g.dout,
+        if (g.kd * g.kh * g.kw <= 3)
+            hipLaunchKernelGGL(conv_c1_taps_kernel<3>, dim3(grid), dim3(256), 0, s, g, (const float*)dy, w, bias, (float*)dx, -1, g.dout,
+                           g.ho, g.wo, g.di, g.hi, g.wi);
+        else
+            hipLaunchKernelGGL(conv_c1_taps_kernel<kSmTaps>, dim3(grid), dim3(256), 0, s, g, (const float*)dy, w, bias, (float*)dx, -1, g.dout,
                            g.ho, g.wo, g.di, g.hi, g.wi);
         return check_launch("conv3d_dgrad(1->1 taps)");
     }
@@ -1771,7 +1782,10 @@ int conv_generic_wgrad(const Mri3dConvGeom& g, const void* x, const void* dy, fl
         MRI3D_REQUIRE(ws != nullptr && ws_bytes >= need, MRI3D_EWORKSPACE, "conv3d_wgrad: workspace %zu < %zu", ws_bytes, need);
         float* part = static_cast<float*>(ws);
         float* bias_part = dbias ? part + (size_t)kC1TBlocks * kSmTaps : nullptr;
-        hipLaunchKernelGGL(conv_c1_taps_wgrad_kernel, dim3(nb), dim3(256), 0, s, g, (const float*)x, (const float*)dy, part, bias_part);
+        if (g.kd * g.kh * g.kw <= 3)
+            hipLaunchKernelGGL(conv_c1_taps_wgrad_kernel<3>, dim3(nb), dim3(256), 0, s, g, (const float*)x, (const float*)dy, part, bias_part);
+        else
+            hipLaunchKernelGGL(conv_c1_taps_wgrad_kernel<kSmTaps>, dim3(nb), dim3(256), 0, s, g, (const float*)x, (const float*)dy, part, bias_part);
         hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(cdiv(taps + 1, 8)), dim3(256), 0, s, part, bias_part, dw, dbias, nb, taps, 1, 1, 1, 1);
         return check_launch("conv3d_wgrad(1->1 taps)");
     }
