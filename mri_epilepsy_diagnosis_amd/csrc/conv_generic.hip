@@ -1433,14 +1433,14 @@ static void launch_fwd(const Mri3dConvGeom& g, const void* x, const float* wp, c
         const int hch = (int)std::max<int64_t>(1, std::min<int64_t>(g.ho, (int64_t)2048 / std::max(g.wo, 1)));
         const int64_t slabs = (int64_t)g.n * g.dout * cdiv(g.ho, hch);
         dim3 tgrid((unsigned)std::min<int64_t>(slabs, 4096), CoP / TL);
+#define MRI3D_FT(NTv, CVv) hipLaunchKernelGGL((conv_fwd_taps_kernel<T, TL, NTv, CVv>), tgrid, dim3(256), 0, s, g, (const T*)x, wp, bias, (T*)y, CoP, hch)
         MRI3D_DISPATCH_DTYPE(g.dtype, T, {
-            if (vec && taps <= 4)
-                hipLaunchKernelGGL((conv_fwd_taps_kernel<T, TL, 4, 4>), tgrid, dim3(256), 0, s, g, (const T*)x, wp, bias, (T*)y, CoP, hch);
-            else if (vec)
-                hipLaunchKernelGGL((conv_fwd_taps_kernel<T, TL, 8, 4>), tgrid, dim3(256), 0, s, g, (const T*)x, wp, bias, (T*)y, CoP, hch);
-            else
-                hipLaunchKernelGGL((conv_fwd_taps_kernel<T, TL, 8, 1>), tgrid, dim3(256), 0, s, g, (const T*)x, wp, bias, (T*)y, CoP, hch);
+            // tap slots = the filter's taps where an instance exists (3: the decoder's k = 3 filters, 6: the encoder's k = 6 ones): a
+            // slot past the filter still costs its address arithmetic and a (cached) load
+            if (vec) { if (taps <= 3) MRI3D_FT(3, 4); else if (taps <= 4) MRI3D_FT(4, 4); else if (taps <= 6) MRI3D_FT(6, 4); else MRI3D_FT(8, 4); }
+            else { if (taps <= 3) MRI3D_FT(3, 1); else if (taps <= 6) MRI3D_FT(6, 1); else MRI3D_FT(8, 1); }
         });
+#undef MRI3D_FT
         return;
     }
     MRI3D_DISPATCH_DTYPE(g.dtype, T, {
@@ -1680,14 +1680,12 @@ static void launch_dgrad(const Mri3dConvGeom& g, const void* dy, const float* wp
         const int hch = (int)std::max<int64_t>(1, std::min<int64_t>(g.hi, (int64_t)2048 / std::max(g.wi, 1)));
         const int64_t slabs = (int64_t)g.n * g.di * cdiv(g.hi, hch);
         dim3 tgrid((unsigned)std::min<int64_t>(slabs, 4096), CiP / TL);
+#define MRI3D_DT(NTv, CVv) hipLaunchKernelGGL((conv_dgrad_taps_kernel<T, TL, NTv, CVv>), tgrid, dim3(256), 0, s, g, (const T*)dy, wp, bias, (T*)dx, CiP, hch)
         MRI3D_DISPATCH_DTYPE(g.dtype, T, {
-            if (vec && taps <= 4)
-                hipLaunchKernelGGL((conv_dgrad_taps_kernel<T, TL, 4, 4>), tgrid, dim3(256), 0, s, g, (const T*)dy, wp, bias, (T*)dx, CiP, hch);
-            else if (vec)
-                hipLaunchKernelGGL((conv_dgrad_taps_kernel<T, TL, 8, 4>), tgrid, dim3(256), 0, s, g, (const T*)dy, wp, bias, (T*)dx, CiP, hch);
-            else
-                hipLaunchKernelGGL((conv_dgrad_taps_kernel<T, TL, 8, 1>), tgrid, dim3(256), 0, s, g, (const T*)dy, wp, bias, (T*)dx, CiP, hch);
+            if (vec) { if (taps <= 3) MRI3D_DT(3, 4); else if (taps <= 4) MRI3D_DT(4, 4); else if (taps <= 6) MRI3D_DT(6, 4); else MRI3D_DT(8, 4); }
+            else { if (taps <= 3) MRI3D_DT(3, 1); else MRI3D_DT(8, 1); }
         });
+#undef MRI3D_DT
         return;
     }
     const int64_t rows = (int64_t)g.n * g.di * g.hi * g.sw;
@@ -1697,7 +1695,9 @@ static void launch_dgrad(const Mri3dConvGeom& g, const void* dy, const float* wp
         const int vt = cdiv(g.kd, g.sd) * cdiv(g.kh, g.sh) * cdiv(g.kw, g.sw);
         if (vec && vt <= 8 && aligned_vec4(g.dtype, dx)) {
             MRI3D_DISPATCH_DTYPE(g.dtype, T, {
-                if (vt <= 4)
+                if (vt <= 3)
+                    hipLaunchKernelGGL((conv_dgrad_strided_taps_kernel<T, TL, 3>), sgrid, dim3(64), 0, s, g, (const T*)dy, wp, bias, (T*)dx, CiP);
+                else if (vt <= 4)
                     hipLaunchKernelGGL((conv_dgrad_strided_taps_kernel<T, TL, 4>), sgrid, dim3(64), 0, s, g, (const T*)dy, wp, bias, (T*)dx, CiP);
                 else
                     hipLaunchKernelGGL((conv_dgrad_strided_taps_kernel<T, TL, 8>), sgrid, dim3(64), 0, s, g, (const T*)dy, wp, bias, (T*)dx, CiP);
