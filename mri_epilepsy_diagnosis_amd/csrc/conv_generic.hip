@@ -845,11 +845,11 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 
 // stage rows [dlo, dlo+ND) x (C1H+2) x (TW+2) of the zero-padded input around tile origin (d0, h0, w0) into LDS
-template <typename T, int TW, int ND>
+template <typename T, int TW, int ND, int NTHR = 256>
 __device__ __forceinline__ void cin1_stage(float* xs, const T* __restrict__ xn, const Mri3dConvGeom& g, int dlo, int h0,
                                            int w0, int tid) {
     constexpr int PW = TW + 4, NE = ND * (C1H + 2) * (TW + 2);
-    for (int e = tid; e < NE; e += 256) {
+    for (int e = tid; e < NE; e += NTHR) {
         const int fw = e % (TW + 2), r = e / (TW + 2);
         const int fh = r % (C1H + 2), fd = r / (C1H + 2);
         const int id = dlo + fd, ih = h0 - 1 + fh, iw = w0 - 1 + fw;
@@ -938,17 +938,20 @@ conv_cin1_fwd_kernel(Mri3dConvGeom g, const T* __restrict__ x, const float* __re
 }
 
 template <typename T, int CO>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(768)
 conv_cin1_wgrad_kernel(Mri3dConvGeom g, const T* __restrict__ x, const T* __restrict__ dy, float* __restrict__ part,
                        float* __restrict__ bias_part, int tilesD, int tilesH, int tilesW, int ntiles, int nshares) {
     constexpr int VPT = Cin1<CO>::VPT, TW = C1WQ * VPT, PW = TW + 4, NA = 9 * CO + CO;
-    __shared__ __attribute__((aligned(16))) float xs[C1D * (C1H + 2) * PW];
-    __shared__ float red[4][NA];
-    const int tid = threadIdx.x;
-    // blockIdx -> (share, kd) with kd fastest inside one XCD's contiguous range (gridDim.x = 3 * nshares, a multiple of 8)
+    __shared__ __attribute__((aligned(16))) float xs[(C1D + 2) * (C1H + 2) * PW];
+    __shared__ float red[12][NA];
+    // One workgroup of 12 waves per share: waves 4 kd .. 4 kd + 3 take the taps of plane kd of the SAME tile — x is staged once for
+    // the three of them and their dy loads, issued within microseconds of each other on one CU, are served from its L1 / L2 (as three
+    // workgroups per share each of them fetched dy: 3 x the gradient tensor, 0.23 ms for 2 x 160x192x160 fp32).
+    const int kd = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 8);
+    const int tid = threadIdx.x & 255;
+    // blockIdx -> share, consecutive shares inside one XCD's contiguous range (gridDim.x = nshares, a multiple of 8)
     const int per_xcd = gridDim.x / 8;
-    const int logical = (blockIdx.x % 8) * per_xcd + blockIdx.x / 8;
-    const int kd = logical % 3, share = logical / 3;
+    const int share = (blockIdx.x % 8) * per_xcd + blockIdx.x / 8;
     const int wq = tid % C1WQ, hl = (tid / C1WQ) % C1H, dl = tid / (C1WQ * C1H);
     f32x2 acc[3][3][CO / 2];   // channel pairs: v_pk_fma_f32
     float bsum[CO];
@@ -969,7 +972,7 @@ conv_cin1_wgrad_kernel(Mri3dConvGeom g, const T* __restrict__ x, const T* __rest
         const int d0 = (t % tilesD) * C1D;
         const int n = t / tilesD;
         __syncthreads();
-        cin1_stage<T, TW, C1D>(xs, x + (int64_t)n * g.di * g.hi * g.wi * g.x_ld, g, d0 + kd - 1, h0, w0, tid);
+        cin1_stage<T, TW, C1D + 2, 768>(xs, x + (int64_t)n * g.di * g.hi * g.wi * g.x_ld, g, d0 - 1, h0, w0, (int)threadIdx.x);
         // this lane's VPT output voxels of dy (zero outside the volume)
         const int od = d0 + dl, oh = h0 + hl;
         f32x2 gy[VPT][CO / 2];
@@ -989,7 +992,7 @@ conv_cin1_wgrad_kernel(Mri3dConvGeom g, const T* __restrict__ x, const T* __rest
         __syncthreads();
 #pragma unroll
         for (int kh = 0; kh < 3; ++kh) {
-            const float* row = xs + (dl * (C1H + 2) + hl + kh) * PW + wq * VPT;
+            const float* row = xs + ((dl + kd) * (C1H + 2) + hl + kh) * PW + wq * VPT;
             float r[VPT + 2];
 #pragma unroll
             for (int i = 0; i < VPT + 2; ++i) r[i] = row[i];
@@ -1010,7 +1013,7 @@ conv_cin1_wgrad_kernel(Mri3dConvGeom g, const T* __restrict__ x, const T* __rest
     }
     // lanes -> wave with DPP adds inside the 16-lane rows + the four row sums (fixed order), waves -> workgroup through LDS
     // (ds_bpermute shuffles here cost 480 LDS round trips per workgroup, 40 % of its run time)
-    const int lane = tid & 63, wave = tid >> 6;
+    const int lane = tid & 63, wave = (int)threadIdx.x >> 6;   // 0 .. 11; waves 4 kd .. 4 kd + 3 hold plane kd's taps
 #pragma unroll
     for (int a = 0; a < 3; ++a)
 #pragma unroll
@@ -1026,12 +1029,13 @@ conv_cin1_wgrad_kernel(Mri3dConvGeom g, const T* __restrict__ x, const T* __rest
         if (lane == 0) red[wave][9 * CO + c] = vsum;
     }
     __syncthreads();
+    const int w0_ = 4 * kd;
     if (tid < 9 * CO) {
-        const float t4 = (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]);
+        const float t4 = (red[w0_][tid] + red[w0_ + 1][tid]) + (red[w0_ + 2][tid] + red[w0_ + 3][tid]);
         part[((size_t)share * 27 + kd * 9 + tid / CO) * CO + tid % CO] = t4;   // part[share][tap][ci = 0][co]
     } else if (tid < NA && kd == 1 && bias_part) {
         const int c = tid - 9 * CO;
-        bias_part[(size_t)share * CO + c] = (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]);
+        bias_part[(size_t)share * CO + c] = (red[w0_][tid] + red[w0_ + 1][tid]) + (red[w0_ + 2][tid] + red[w0_ + 3][tid]);
     }
 }
 
@@ -1800,10 +1804,10 @@ int conv_generic_wgrad(const Mri3dConvGeom& g, const void* x, const void* dy, fl
         // every (share, kd) workgroup writes its slots, also when its share of the tiles is empty (zeros)
         MRI3D_DISPATCH_DTYPE(g.dtype, T, {
             if (g.co == 8)
-                hipLaunchKernelGGL((conv_cin1_wgrad_kernel<T, 8>), dim3(3 * kCin1Shares), dim3(256), 0, s, g, (const T*)x,
+                hipLaunchKernelGGL((conv_cin1_wgrad_kernel<T, 8>), dim3(kCin1Shares), dim3(768), 0, s, g, (const T*)x,
                                    (const T*)dy, part, bias_part, tilesD, tilesH, tilesW, ntiles, kCin1Shares);
             else
-                hipLaunchKernelGGL((conv_cin1_wgrad_kernel<T, 16>), dim3(3 * kCin1Shares), dim3(256), 0, s, g, (const T*)x,
+                hipLaunchKernelGGL((conv_cin1_wgrad_kernel<T, 16>), dim3(kCin1Shares), dim3(768), 0, s, g, (const T*)x,
                                    (const T*)dy, part, bias_part, tilesD, tilesH, tilesW, ntiles, kCin1Shares);
         });
         hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(cdiv(27 * g.co + g.co, 8)), dim3(256), 0, s, part, bias_part, dw, dbias,
