@@ -231,3 +231,26 @@ def test_bench_launcher_propagates_rank_failure():
     res = _run_bench(["--gpus", "2", "--steps", "1", "--warmup", "0"])
     assert res.returncode != 0 and not [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
     assert "ROCm device" in res.stderr
+
+
+def test_fused_operator_predicates_decline_host_tensors_without_touching_the_library():
+    """ops.upsample_conv3d_supported / ops.conv3d_pair_supported are pure host decisions: a CPU tensor, a non-integer scale, a
+    strided convolution after the upsampling, an input that needs its gradient or an active autocast region all mean "run the
+    two operators" — decided before any C-ABI call."""
+    import types
+
+    import torch
+
+    from mri_epilepsy_diagnosis_amd import ops
+
+    x = torch.zeros(1, 8, 2, 3, 4)
+    w = torch.zeros(1, 8, 3, 1, 1)
+    assert not ops.upsample_conv3d_supported(x, w, 4, 1, (1, 0, 0), 1)          # host tensor
+    assert not ops.upsample_conv3d_supported(x, w, 2.5, 1, (1, 0, 0), 1)        # non-integer scale
+    assert not ops.upsample_conv3d_supported(x, w, 4, 2, (1, 0, 0), 1)          # strided convolution
+    assert not ops.upsample_conv3d_supported(x, torch.zeros(1, 4, 3, 1, 1), 4, 1, 0, 1)   # channel mismatch
+    c1 = types.SimpleNamespace(weight=torch.zeros(8, 1, 6, 1, 1), bias=None, stride=(2, 1, 1), padding=(2, 0, 0), dilation=(1, 1, 1))
+    c2 = types.SimpleNamespace(weight=torch.zeros(8, 8, 1, 6, 1), bias=None, stride=(1, 2, 1), padding=(0, 2, 0), dilation=(1, 1, 1))
+    assert not ops.conv3d_pair_supported(torch.zeros(1, 1, 8, 8, 8), c1, c2)    # host tensor
+    assert not ops.conv3d_pair_supported(torch.zeros(1, 1, 8, 8), c1, c2)       # not 5-D
+
