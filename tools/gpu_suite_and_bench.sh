@@ -1,7 +1,7 @@
 #!/bin/bash
-# full GPU suite + both bench lines (+ optional model bench)
+# full GPU suite + both bench lines:  gpurun --timeout 1100 -- "bash tools/gpu_suite_and_bench.sh TAG"  ->  gpurun_out/TAG/
 set -o pipefail
-O=gpurun_out/${1:-r03_full}
+O=gpurun_out/${1:-suite}
 mkdir -p $O
 python -m pytest tests -m gpu -x -q > $O/pytest.log 2>&1; rc=$?; echo "pytest rc=$rc" | tee $O/pytest.rc; tail -5 $O/pytest.log
 [ $rc -eq 0 ] || exit $rc
