@@ -169,6 +169,7 @@ extern "C" int mri3d_convpair_wgrad_first(const Mri3dConvGeom* first, const Mri3
     MRI3D_REQUIRE(convpair_ok(*first, *second), MRI3D_ENOTSUP, "convpair_wgrad_first: geometry not served (see mri3d_convpair_supported)");
     MRI3D_REQUIRE(workspace && ws_bytes >= mri3d_convpair_workspace_bytes(first, second), MRI3D_EINVAL,
                   "convpair_wgrad_first: workspace too small");
+    MRI3D_REQUIRE(aligned_vec4(first->dtype, dy2), MRI3D_EINVAL, "convpair_wgrad_first: dy2 must be aligned to four channels");
     hipStream_t s = static_cast<hipStream_t>(stream);
     const Mri3dConvGeom &a = *first, &b = *second;
     const int64_t rows = (int64_t)a.n * a.dout * a.ho;   // (n, d1, h)

@@ -306,6 +306,7 @@ extern "C" int mri3d_upconv3d_fwd(const Mri3dConvGeom* g, int32_t scale, const v
                                   mri3d_stream_t stream) {
     MRI3D_REQUIRE(g && x && w && y, MRI3D_EINVAL, "upconv3d_fwd: null pointer");
     MRI3D_REQUIRE(upconv_ok(*g, scale), MRI3D_ENOTSUP, "upconv3d_fwd: geometry not served (see mri3d_upconv3d_supported)");
+    MRI3D_REQUIRE(aligned_vec4(g->dtype, x), MRI3D_EINVAL, "upconv3d_fwd: x must be aligned to four channels");
     hipStream_t s = static_cast<hipStream_t>(stream);
     const int hch = upconv_hch(*g);
     const int64_t slabs = (int64_t)g->n * g->dout * cdiv(g->ho, hch);
@@ -332,6 +333,7 @@ extern "C" int mri3d_upconv3d_dgrad(const Mri3dConvGeom* g, int32_t scale, const
                                     mri3d_stream_t stream) {
     MRI3D_REQUIRE(g && dy && w && dx, MRI3D_EINVAL, "upconv3d_dgrad: null pointer");
     MRI3D_REQUIRE(upconv_ok(*g, scale), MRI3D_ENOTSUP, "upconv3d_dgrad: geometry not served (see mri3d_upconv3d_supported)");
+    MRI3D_REQUIRE(aligned_vec4(g->dtype, dx), MRI3D_EINVAL, "upconv3d_dgrad: dx must be aligned to four channels");
     hipStream_t s = static_cast<hipStream_t>(stream);
     const int64_t rows = (int64_t)g->n * (g->di / scale) * (g->hi / scale);
     MRI3D_REQUIRE(rows <= 0x7fffffff, MRI3D_ENOTSUP, "upconv3d_dgrad: too many coarse rows");
@@ -358,6 +360,7 @@ extern "C" int mri3d_upconv3d_wgrad(const Mri3dConvGeom* g, int32_t scale, const
                                     void* workspace, size_t ws_bytes, mri3d_stream_t stream) {
     MRI3D_REQUIRE(g && x && dy && dw, MRI3D_EINVAL, "upconv3d_wgrad: null pointer");
     MRI3D_REQUIRE(upconv_ok(*g, scale), MRI3D_ENOTSUP, "upconv3d_wgrad: geometry not served (see mri3d_upconv3d_supported)");
+    MRI3D_REQUIRE(aligned_vec4(g->dtype, x), MRI3D_EINVAL, "upconv3d_wgrad: x must be aligned to four channels");
     MRI3D_REQUIRE(workspace && ws_bytes >= mri3d_upconv3d_workspace_bytes(g, scale), MRI3D_EINVAL, "upconv3d_wgrad: workspace too small");
     hipStream_t s = static_cast<hipStream_t>(stream);
     const int taps = g->kd * g->kh * g->kw;

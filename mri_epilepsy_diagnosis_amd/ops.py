@@ -1224,6 +1224,8 @@ def upsample_conv3d_supported(x, weight, scale, stride=1, padding=0, dilation=1)
     scale = int(scale)
     if _triple(stride) != (1, 1, 1) or _triple(dilation) != (1, 1, 1) or x.dim() != 5 or not x.is_cuda:
         return False
+    if x.data_ptr() % 16:      # a channel slice that does not start on four channels: the two operators take it
+        return False
     n, c, d, h, w = x.shape
     if weight.shape[1] != c:
         return False
