@@ -304,7 +304,8 @@ UP_CASES = [("nearest", None, 2, None, 16, (5, 6, 7)), ("nearest", None, 4, None
             # 8 / 4 / 2 / 1 pieces per voxel, a half-empty second channel pass (24 channels), two full passes (64)
             ("trilinear", None, 2, False, 64, (18, 9, 19)), ("trilinear", None, 2, False, 24, (3, 5, 33)),
             ("trilinear", None, 2, False, 16, (17, 4, 16)), ("trilinear", None, 2, False, 8, (2, 7, 5)),
-            ("trilinear", None, 2, False, 4, (33, 3, 18))]
+            ("trilinear", None, 2, False, 4, (33, 3, 18)), ("trilinear", None, 2, False, 4, (1, 3, 5)), ("trilinear", None, 2, False, 8, (2, 1, 1)),
+            ("trilinear", None, 2, False, 12, (5, 1, 21))]
 
 
 @pytest.mark.parametrize("mode,size,scale,ac,c,sp", UP_CASES)
