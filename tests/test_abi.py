@@ -72,6 +72,19 @@ def test_workspace_queries_are_host_only():
     g = _lib.ConvGeom(2, 160, 192, 160, 48, 160, 192, 160, 16, 3, 3, 3, 1, 1, 1, 1, 1, 1, 1, 1, 1, 48, 16, 0)
     for p in (0, 1, 2):
         assert L.mri3d_conv3d_workspace_bytes(ctypes.byref(g), p) > 0
+    # the fused autoencoder operators (round 3): predicates and workspace sizes are host decisions too
+    # Conv3d(8, 1, (3,1,1), padding (1,0,0)) over a 4x nearest upsampling of 40x48x40 -> the virtual fine input 160x192x160
+    up = _lib.ConvGeom(4, 160, 192, 160, 8, 160, 192, 160, 1, 3, 1, 1, 1, 1, 1, 1, 0, 0, 1, 1, 1, 8, 1, 0)
+    assert L.mri3d_upconv3d_supported(ctypes.byref(up), 4) == 1 and L.mri3d_upconv3d_workspace_bytes(ctypes.byref(up), 4) > 0
+    assert L.mri3d_upconv3d_supported(ctypes.byref(up), 3) == 0 and L.mri3d_upconv3d_workspace_bytes(ctypes.byref(up), 3) == 0
+    wide = _lib.ConvGeom(4, 40, 48, 40, 16, 40, 48, 40, 8, 3, 1, 1, 1, 1, 1, 1, 0, 0, 1, 1, 1, 16, 8, 0)
+    assert L.mri3d_upconv3d_supported(ctypes.byref(wide), 4) == 0          # 16 -> 8: no instance, the caller keeps the two operators
+    # Conv3d(1, 8, (6,1,1), s (2,1,1), p (2,0,0)) then Conv3d(8, 8, (1,6,1), s (1,2,1), p (0,2,0)) on 160x192x160
+    first = _lib.ConvGeom(4, 160, 192, 160, 1, 80, 192, 160, 8, 6, 1, 1, 2, 1, 1, 2, 0, 0, 1, 1, 1, 1, 8, 0)
+    second = _lib.ConvGeom(4, 80, 192, 160, 8, 80, 96, 160, 8, 1, 6, 1, 1, 2, 1, 0, 2, 0, 1, 1, 1, 8, 8, 0)
+    assert L.mri3d_convpair_supported(ctypes.byref(first), ctypes.byref(second)) == 1
+    assert L.mri3d_convpair_workspace_bytes(ctypes.byref(first), ctypes.byref(second)) > 0
+    assert L.mri3d_convpair_supported(ctypes.byref(second), ctypes.byref(first)) == 0
 
 
 def test_host_code_is_clean_under_address_and_ub_sanitizers():
