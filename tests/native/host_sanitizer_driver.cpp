@@ -159,6 +159,44 @@ int main() {
         loc[3 * 150 + 1] = 1000;   // h origin outside the volume
         EXPECT(mri3d_extract_patches(P, 4, 1, 64, 64, 64, loc.data(), 200, 32, 32, 32, P, nullptr) != MRI3D_OK);
     }
+    {   // fused autoencoder operators (round 3): predicates, workspace sizes and every refusal are host-side
+        Mri3dConvGeom up;
+        memset(&up, 0, sizeof(up));
+        up.n = 4; up.di = 160; up.hi = 192; up.wi = 160; up.ci = 8; up.dout = 160; up.ho = 192; up.wo = 160; up.co = 1;
+        up.kd = 3; up.kh = 1; up.kw = 1; up.sd = up.sh = up.sw = 1; up.pd = 1; up.dd = up.dh = up.dw = 1; up.x_ld = 8; up.y_ld = 1;
+        EXPECT(mri3d_upconv3d_supported(&up, 4) == 1 && mri3d_upconv3d_supported(&up, 2) == 1 && mri3d_upconv3d_supported(&up, 3) == 0);
+        EXPECT(mri3d_upconv3d_supported(nullptr, 4) == 0 && mri3d_upconv3d_workspace_bytes(nullptr, 4) == 0);
+        EXPECT(mri3d_upconv3d_workspace_bytes(&up, 4) > 0);
+        EXPECT(mri3d_upconv3d_fwd(&up, 4, nullptr, (const float*)P, nullptr, P, nullptr) == MRI3D_EINVAL);
+        EXPECT(mri3d_upconv3d_fwd(&up, 3, P, (const float*)P, nullptr, P, nullptr) == MRI3D_ENOTSUP);
+        EXPECT(mri3d_upconv3d_dgrad(&up, 4, P, nullptr, P, nullptr) == MRI3D_EINVAL);
+        std::vector<float> b3(64);
+        float* q = b3.data();
+        EXPECT(mri3d_upconv3d_fwd(&up, 4, q + 1, q, nullptr, q, nullptr) == MRI3D_EINVAL);                 // x off four channels
+        EXPECT(mri3d_upconv3d_wgrad(&up, 4, q, q, q, q, q, 16, nullptr) == MRI3D_EINVAL);                   // workspace too small
+        Mri3dConvGeom bad2 = up;
+        bad2.sd = 2;
+        EXPECT(mri3d_upconv3d_supported(&bad2, 4) == 0);                                                    // strided convolution
+        bad2 = up; bad2.ci = 16; bad2.co = 8; bad2.x_ld = 16; bad2.y_ld = 8;
+        EXPECT(mri3d_upconv3d_supported(&bad2, 4) == 0);                                                    // no (16, 8, 3) instance
+        Mri3dConvGeom first, second;
+        memset(&first, 0, sizeof(first));
+        first.n = 4; first.di = 160; first.hi = 192; first.wi = 160; first.ci = 1; first.dout = 80; first.ho = 192; first.wo = 160; first.co = 8;
+        first.kd = 6; first.kh = 1; first.kw = 1; first.sd = 2; first.sh = first.sw = 1; first.pd = 2; first.dd = first.dh = first.dw = 1;
+        first.x_ld = 1; first.y_ld = 8;
+        second = first;
+        second.di = 80; second.ci = 8; second.dout = 80; second.ho = 96; second.kd = 1; second.kh = 6; second.sd = 1; second.sh = 2;
+        second.pd = 0; second.ph = 2; second.x_ld = 8; second.y_ld = 8;
+        EXPECT(mri3d_convpair_supported(&first, &second) == 1 && mri3d_convpair_supported(&second, &first) == 0);
+        EXPECT(mri3d_convpair_supported(nullptr, &second) == 0 && mri3d_convpair_workspace_bytes(&first, nullptr) == 0);
+        EXPECT(mri3d_convpair_workspace_bytes(&first, &second) > 0);
+        EXPECT(mri3d_convpair_wgrad_first(&first, &second, nullptr, P, (const float*)P, (float*)P, nullptr, P, 0, nullptr) == MRI3D_EINVAL);
+        EXPECT(mri3d_convpair_wgrad_first(&second, &first, P, P, (const float*)P, (float*)P, nullptr, P, 0, nullptr) == MRI3D_ENOTSUP);
+        EXPECT(mri3d_convpair_wgrad_first(&first, &second, q, q, q, q, nullptr, q, 16, nullptr) == MRI3D_EINVAL);   // workspace too small
+        Mri3dConvGeom s3 = second;
+        s3.sh = 1; s3.ho = 191;   // six taps at stride 1 reach a row through six taps: more than the kernel's three slots
+        EXPECT(mri3d_convpair_supported(&first, &s3) == 0);
+    }
     if (g_fail) {
         fprintf(stderr, "%d host checks failed\n", g_fail);
         return 1;
