@@ -1926,13 +1926,18 @@ conv_mfma_wgrad_bf16_kernel(const bf16_t* __restrict__ x, const bf16_t* __restri
 // W-neighbouring columns — a column takes the products of ITS X voxels, with dY[w0-1] and dY[w0+32] read from the neighbours
 // (zero outside the volume) — so X has no W halo and dY a one-voxel one.  Tasks = (sample, d-segment, column); accumulators
 // (27 taps x (16 ci x 16 co) per wave, +1 for dbias fed with A = 1) and partial layout as in the tile kernel.
-//   LDS: X planes in a ring of five (10 rows x 1 KiB), dY planes in a ring of three (8 rows x 34 voxels, 1 088 B per row).
-//   step t:  wait for the wave's pieces of step t-2 (counted vmcnt: the pieces of step t-1 may still fly), barrier,
-//            issue X plane t+3 and dY plane t+2 (19 pieces of 1 KiB per workgroup, 5 or 4 per wave, per-lane offsets constant
+//   LDS: X planes (10 rows x 1 KiB) and dY planes (8 rows x 34 voxels, 1 088 B per row) in rings of four: the plane being
+//   read + three in flight.  A wave keeps the X fragments of planes t-1 and t in REGISTERS from the steps that read them, so
+//   LDS holds one live plane of each tensor instead of three + one: the same 78 KB carry three planes of lead instead of two —
+//   on one-ci-tile layers the kernel's rate is (bytes in flight) / (loaded latency, ~3.7 us), DESIGN.md §4.4.
+//   step t:  wait for the wave's pieces of step t-3 (counted vmcnt: those of steps t-2 and t-1 may still fly), barrier,
+//            issue X plane t+4 and dY plane t+3 (19 pieces of 1 KiB per workgroup, 5 or 4 per wave, per-lane offsets constant
 //            for the column; a plane outside the segment's range is a resource of zero records: zeros),
-//            multiply plane t: X planes t-1, t, t+1, dY plane t.
+//            read the fragments of X plane t+1, multiply plane t (X planes t-1, t from registers, t+1; dY plane t).
 // Measured against the register-staged kernel (tools/r03_wgt.sh, one box): 48 -> 16 0.590 -> 0.503 ms, 16 -> 16 0.232 -> 0.195,
-// 8 -> 16 0.215 -> 0.180, 96 -> 32 at 80x96x80 0.358 -> 0.302, 16 -> 16 at 512 x 32^3 0.333 -> 0.287.  What binds it now is the
+// 8 -> 16 0.215 -> 0.180, 96 -> 32 at 80x96x80 0.358 -> 0.302, 16 -> 16 at 512 x 32^3 0.333 -> 0.287 with rings of five / three
+// planes and two planes of lead; with the X fragments of two planes in registers and three planes of lead 0.457 / 0.186 / 0.168 /
+// 0.291 / 0.26 ms.  What binds it is the
 // fabric: with the MFMAs compiled out the 48 -> 16 layer still takes 0.415 ms (its three ci-tile workgroups each fetch dY: PMC
 // 2.0x the algorithmic bytes, 5 TB/s), with the DMA compiled out 0.280 ms; with every workgroup on one L2-resident column the
 // DMA alone runs at 14 TB/s.  (Workgroups of one task's ci-tiles share an XCD — tools/microbench/xcc_probe.hip — yet run in lock
@@ -1941,15 +1946,15 @@ conv_mfma_wgrad_bf16_kernel(const bf16_t* __restrict__ x, const bf16_t* __restri
 // parity-green but slower: 0.72 ms with six waves of four rows (one or two waves per SIMD expose every fragment read and the
 // step barrier), and twelve waves of two rows do not fit 170 registers: hipcc spills inside the MFMA loop.)
 constexpr int MTH = 8, MXR = MTH + 2;                 // output rows / X rows per plane
-constexpr int kMarchSeg = 40;                         // planes per task at most (4 fill steps per task); shorter for small volumes
+constexpr int kMarchSeg = 40;                         // planes per task at most (5 fill steps per task); shorter for small volumes
 constexpr int TXROW = BTW * 32;                       //  1 024 B  one X row: 32 voxels x 16 channels
 constexpr int TXP = MXR * TXROW;                      // 10 240 B  one X plane
-constexpr int TXSLOTS = 5;
+constexpr int TXSLOTS = 4;                            //           ring: the plane being read + three in flight
 constexpr int TYROW = (BTW + 2) * 32;                 //  1 088 B  one dY row with its two W-halo voxels
 constexpr int TYPIECES = (MTH * TYROW + 1023) / 1024; //  9 pieces of 1 KiB (the ninth: lanes 0..31)
 constexpr int TYP = TYPIECES * 1024;                  //  9 216 B  one dY plane (8 704 used)
-constexpr int TYSLOTS = 3;
-constexpr int TLDS = TXSLOTS * TXP + TYSLOTS * TYP;   // 78 848 B: two workgroups per CU
+constexpr int TYSLOTS = 4;
+constexpr int TLDS = TXSLOTS * TXP + TYSLOTS * TYP;   // 77 824 B: two workgroups per CU
 constexpr int TNPC = (MXR + TYPIECES + 3) / 4;        // DMA pieces per wave and step at most (5)
 
 typedef short s16x4_t __attribute__((ext_vector_type(4)));
@@ -2033,17 +2038,20 @@ conv_mfma_wgrad_bf16t_kernel(const bf16_t* __restrict__ x, const bf16_t* __restr
             rs[3] = 0x00020000;
             return rs;
         };
-        const int t0 = dA - 4;
-        int sx = ((t0 + 3) % TXSLOTS + TXSLOTS) % TXSLOTS;   // ring slot of X plane t + 3
-        int sy = ((t0 + 2) % TYSLOTS + TYSLOTS) % TYSLOTS;   // ring slot of dY plane t + 2
+        // X fragments of planes t-1 and t stay in registers from the steps that read them: the LDS keeps ONE live plane of X and
+        // of dY and three in flight of each (lead 3 instead of 2 in the same 78 KB)
+        const int t0 = dA - 5;
+        int sx = ((t0 + 4) % TXSLOTS + TXSLOTS) % TXSLOTS;   // ring slot of X plane t + 4
+        int sy = ((t0 + 3) % TYSLOTS + TYSLOTS) % TYSLOTS;   // ring slot of dY plane t + 3
+        bf16x8_t xfA[4], xfB[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) xfA[i] = xfB[i] = ones;
         for (int t = t0; t < dB; ++t) {
-            // ---- the wave's pieces of step t-2 have landed (those of step t-1 are younger), then every wave's
-            if (wv == 3) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+            if (wv == 3) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
             asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-            // ---- issue X plane t+3 (its slot held plane t-2) and dY plane t+2 (its slot held plane t-1)
             {
-                const int qx = t + 3, qy = t + 2;
+                const int qx = t + 4, qy = t + 3;
                 const i32x4 rsx = rsrc(xorg + (unsigned long long)((int64_t)qx * xplane), qx >= xlo && qx <= xhi);
                 const i32x4 rsy = rsrc(yorg + (unsigned long long)((int64_t)qy * yplane), qy >= dA && qy < dB);
                 const unsigned xdst = xs0 + (unsigned)(sx * TXP), ydst = ys0 + (unsigned)(sy * TYP);
@@ -2056,44 +2064,43 @@ conv_mfma_wgrad_bf16t_kernel(const bf16_t* __restrict__ x, const bf16_t* __restr
                         if (lane < (MTH * TYROW - (TYPIECES - 1) * 1024) / 16) lds_dma16(vof[i], rsy, ydst + (unsigned)((id - MXR) * 1024));
                     }
                 }
-                sx = sx + 1 == TXSLOTS ? 0 : sx + 1;
-                sy = sy + 1 == TYSLOTS ? 0 : sy + 1;
+                sx = sx + 1 == TXSLOTS ? 0 : sx + 1;   // now the slot of plane t+5 = the slot of plane t+1
+                sy = sy + 1 == TYSLOTS ? 0 : sy + 1;   // now the slot of plane t+4 = the slot of plane t
             }
-            // ---- multiply plane t: X plane t-1+kd is two / one / zero slots behind the one just issued ... (sx now = slot of plane t+4)
-            if (t >= dA) {
-                // slot of X plane q = (sx + q - (t + 4)) mod 5; dY plane t = (sy + t - (t + 3)) mod 3 = sy
-                const int sxm = sx;                      // plane t-1: sx - 5 = sx
-                const int sx0 = sxm + 1 >= TXSLOTS ? sxm + 1 - TXSLOTS : sxm + 1;
-                const int sx1 = sx0 + 1 >= TXSLOTS ? sx0 + 1 - TXSLOTS : sx0 + 1;
-                const unsigned yb = yfrag + (unsigned)(sy * TYP);
-                bf16x8_t dyf[2][3];
+            if (t >= dA - 2) {
+                bf16x8_t xfC[4];
+                const unsigned xb = xfrag + (unsigned)(sx * TXP);
 #pragma unroll
-                for (int r = 0; r < 2; ++r)
-#pragma unroll
-                    for (int kw = 0; kw < 3; ++kw) dyf[r][kw] = tr_frag(yb + (unsigned)(r * TYROW + 32 * (1 - kw)));   // dY[u + 1 - kw]
-                if constexpr (BIAS) {
-                    acc[TG] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, dyf[0][1], acc[TG], 0, 0, 0);
-                    acc[TG] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, dyf[1][1], acc[TG], 0, 0, 0);
-                }
-#pragma unroll
-                for (int kd = 0; kd < 3; ++kd) {
-                    const unsigned xb = xfrag + (unsigned)((kd == 0 ? sxm : kd == 1 ? sx0 : sx1) * TXP);
-                    bf16x8_t xf[4];
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) xf[i] = tr_frag(xb + (unsigned)(i * TXROW));
+                for (int i = 0; i < 4; ++i) xfC[i] = tr_frag(xb + (unsigned)(i * TXROW));
+                if (t >= dA) {
+                    const unsigned yb = yfrag + (unsigned)(sy * TYP);
+                    bf16x8_t dyf[2][3];
 #pragma unroll
                     for (int r = 0; r < 2; ++r)
 #pragma unroll
-                        for (int kh = 0; kh < 3; ++kh)
+                        for (int kw = 0; kw < 3; ++kw) dyf[r][kw] = tr_frag(yb + (unsigned)(r * TYROW + 32 * (1 - kw)));   // dY[u + 1 - kw]
+                    if constexpr (BIAS) {
+                        acc[TG] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, dyf[0][1], acc[TG], 0, 0, 0);
+                        acc[TG] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, dyf[1][1], acc[TG], 0, 0, 0);
+                    }
 #pragma unroll
-                            for (int kw = 0; kw < 3; ++kw)
-                                acc[(kd * 3 + kh) * 3 + kw] =
-                                    __builtin_amdgcn_mfma_f32_16x16x32_bf16(xf[r + kh], dyf[r][kw], acc[(kd * 3 + kh) * 3 + kw], 0, 0, 0);
+                    for (int kd = 0; kd < 3; ++kd)
+#pragma unroll
+                        for (int r = 0; r < 2; ++r)
+#pragma unroll
+                            for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+                                for (int kw = 0; kw < 3; ++kw) {
+                                    const bf16x8_t a = kd == 0 ? xfA[r + kh] : kd == 1 ? xfB[r + kh] : xfC[r + kh];
+                                    acc[(kd * 3 + kh) * 3 + kw] =
+                                        __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, dyf[r][kw], acc[(kd * 3 + kh) * 3 + kw], 0, 0, 0);
+                                }
                 }
+#pragma unroll
+                for (int i = 0; i < 4; ++i) { xfA[i] = xfB[i]; xfB[i] = xfC[i]; }
             }
         }
     }
-
     // every DMA piece has landed (the last steps' zero planes too), every wave is done reading: the ring becomes the reduction buffer
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
     float* red = lds;  // [TGA][256]
